@@ -1,0 +1,132 @@
+/*
+ * medtutor_retrieval.h -- C ABI of the MI355X-native local dense retriever.
+ *
+ * The reference (yale-nlp/medical-rag, "MedTutor") has no FFI of its own for
+ * this path: its boundary is the Python surface of pipeline/utils/local_rag.py.
+ * Each entry point below names the reference lines whose work it takes over;
+ * the Python module medical-rag_amd/local_rag.py binds them with ctypes and
+ * keeps the reference's four function names.
+ *
+ * Conventions
+ *  - C linkage, plain pointers and sizes, no exceptions cross the boundary.
+ *  - Return value: MTR_OK or a negative MTR_ERR_* code; mtr_last_error()
+ *    returns a thread-local message for the last failing call.
+ *  - An index handle owns one device-resident row shard on ONE GPU: rows are
+ *    stored row-major, L2-normalised (when asked), fp32 or bf16, with the row
+ *    stride padded to a multiple of 16 bytes.  Row ids reported by a search
+ *    are  row_offset + local row  (int64), so shards of one corpus on several
+ *    GPUs (one process per GPU) report global ids.
+ *  - Result rows are ordered by (score descending, row id ascending); slots
+ *    beyond the number of rows hold id -1 and score -inf.
+ *  - Calls on one handle are serialised by an internal mutex.
+ */
+#ifndef MEDTUTOR_RETRIEVAL_H
+#define MEDTUTOR_RETRIEVAL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mtr_index mtr_index_t;
+
+enum {
+    MTR_OK = 0,
+    MTR_ERR_INVALID = -1,   /* bad argument / unsupported size */
+    MTR_ERR_NONFINITE = -2, /* NaN or infinity in rows or queries (sklearn raises ValueError) */
+    MTR_ERR_HIP = -3,       /* HIP runtime error */
+    MTR_ERR_COMM = -4,      /* reserved: collective error */
+    MTR_ERR_OOM = -5        /* device allocation failed */
+};
+
+enum { MTR_F32 = 0, MTR_F64 = 1, MTR_BF16 = 2 };
+enum { MTR_COSINE = 0, MTR_IP = 1 };
+
+#define MTR_MAX_K 1024
+
+/* Allocates an empty shard of n rows x d columns on GPU device_id.
+ * store_dtype: MTR_F32 or MTR_BF16.  normalize != 0: rows are L2-normalised
+ * as they are loaded (norms below 10*DBL_EPSILON count as 1, as scikit-learn's
+ * normalize does), which is what lets cosine search run as a pure inner
+ * product.  Takes over the device-side half of load_embeddings
+ * (pipeline/utils/local_rag.py:90-101) and the per-call float64 matrix rebuild
+ * of retrieve_top_index (pipeline/utils/local_rag.py:76). */
+int mtr_index_alloc(int64_t n, int32_t d, int32_t store_dtype, int32_t normalize,
+                    int32_t device_id, int64_t row_offset, mtr_index_t** out);
+
+/* Converts n_rows rows (src_dtype MTR_F32/F64/BF16, dense row-major, d
+ * columns) into the shard starting at local row row_start: finiteness check,
+ * optional normalisation, cast, pad.  rows_on_device != 0: `rows` is a device
+ * pointer on the shard's GPU; otherwise a host pointer (copied in chunks).
+ * Returns MTR_ERR_NONFINITE when a NaN/inf was seen (rows are then unusable).
+ * Replaces the row normalisation inside sklearn cosine_similarity as called at
+ * pipeline/utils/local_rag.py:77, done once instead of per query. */
+int mtr_index_load_rows(mtr_index_t* index, int64_t row_start, const void* rows, int64_t n_rows,
+                        int32_t src_dtype, int32_t rows_on_device);
+
+/* mtr_index_alloc + mtr_index_load_rows of all n rows from host memory. */
+int mtr_index_create(const void* host_rows, int64_t n, int32_t d, int32_t src_dtype,
+                     int32_t store_dtype, int32_t normalize, int32_t device_id,
+                     int64_t row_offset, mtr_index_t** out);
+
+/* Exact top-k of b queries against the shard; blocks until out_idx[b*k] and
+ * out_score[b*k] (host memory) are filled.  queries: b x d dense row-major,
+ * q_dtype MTR_F32/F64/BF16, host pointer or (queries_on_device != 0) device
+ * pointer.  metric MTR_COSINE normalises each query (the shard must have been
+ * built with normalize != 0); MTR_IP uses the queries as given.
+ * Replaces retrieve_top_index (pipeline/utils/local_rag.py:71-78): column 0 of
+ * the result is that function's return value; columns 1..k-1 extend its
+ * np.argmax tie rule (lowest row first). */
+int mtr_index_search(mtr_index_t* index, const void* queries, int32_t q_dtype,
+                     int32_t queries_on_device, int32_t b, int32_t k, int32_t metric,
+                     int64_t* out_idx, float* out_score);
+
+/* Same search with device-resident queries and outputs, enqueued on `stream`
+ * (a hipStream_t; NULL = HIP's default stream) without synchronising.  The
+ * caller synchronises the stream before reading dev_out_*.  Query values are
+ * not checked for NaN/inf on this path.  Used by the multi-GPU path (local
+ * candidates feed the all-gather) and by benchmarks. */
+int mtr_index_search_device(mtr_index_t* index, const void* dev_queries, int32_t q_dtype,
+                            int32_t b, int32_t k, int32_t metric,
+                            int64_t* dev_out_idx, float* dev_out_score, void* stream);
+
+/* k-way merge of per-shard candidate lists on GPU device_id: inputs are
+ * n_lists blocks of b x k_in (id, score) pairs laid out [list][b][k_in] --
+ * exactly what an all-gather of each rank's mtr_index_search_device output
+ * produces; ids < 0 are padding.  Writes the best k_out per query ordered by
+ * (score desc, id asc).  This is the exchange step of the row-sharded search;
+ * the reference is single-shard (pipeline/utils/local_rag.py:78 is its whole
+ * "merge"). */
+int mtr_merge_topk_device(const int64_t* dev_idx, const float* dev_score, int32_t n_lists,
+                          int32_t b, int32_t k_in, int32_t k_out,
+                          int64_t* dev_out_idx, float* dev_out_score,
+                          int32_t device_id, void* stream);
+
+/* Shape and storage of a shard. Any out pointer may be NULL. */
+int mtr_index_info(const mtr_index_t* index, int64_t* n, int32_t* d, int32_t* store_dtype,
+                   int32_t* normalized, int32_t* device_id, int64_t* row_offset);
+
+/* Copies rows [row_start, row_start+n_rows) back to host as fp32 (n_rows x d),
+ * as stored (normalised, rounded to the storage type).  For parity tests. */
+int mtr_index_read_rows(mtr_index_t* index, int64_t row_start, int64_t n_rows, float* host_out);
+
+/* Per-launch HIP-event timing of the scoring kernel (the scan over the rows),
+ * recorded on the stream it is launched on.  enable != 0 starts recording (and
+ * clears earlier samples); mtr_index_scan_time synchronises the recorded
+ * events and returns their count and total milliseconds. */
+int mtr_index_profile(mtr_index_t* index, int32_t enable);
+int mtr_index_scan_time(mtr_index_t* index, int32_t* n_launches, double* total_ms);
+
+void mtr_index_destroy(mtr_index_t* index);
+
+/* Thread-local message of the last failing call on this thread ("" if none). */
+const char* mtr_last_error(void);
+
+/* Library version string. */
+const char* mtr_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MEDTUTOR_RETRIEVAL_H */

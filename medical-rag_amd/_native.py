@@ -1,0 +1,262 @@
+"""ctypes binding of libmedtutor_retrieval.so (C ABI: include/medtutor_retrieval.h).
+
+There is no CPU fallback: if the library is missing or a HIP call fails the
+caller gets an exception.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+LIB_NAME = "libmedtutor_retrieval.so"
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+
+MTR_OK, MTR_ERR_INVALID, MTR_ERR_NONFINITE, MTR_ERR_HIP, MTR_ERR_COMM, MTR_ERR_OOM = 0, -1, -2, -3, -4, -5
+MTR_F32, MTR_F64, MTR_BF16 = 0, 1, 2
+MTR_COSINE, MTR_IP = 0, 1
+MTR_MAX_K = 1024
+
+METRICS = {"cosine": MTR_COSINE, "ip": MTR_IP}
+STORE_DTYPES = {"fp32": MTR_F32, "f32": MTR_F32, "float32": MTR_F32, "bf16": MTR_BF16, "bfloat16": MTR_BF16}
+
+_i32, _i64, _vp = C.c_int32, C.c_int64, C.c_void_p
+_pp = C.POINTER(C.c_void_p)
+
+# name -> (restype, argtypes); every symbol the header declares.
+SIGNATURES = {
+    "mtr_index_alloc": (_i32, [_i64, _i32, _i32, _i32, _i32, _i64, _pp]),
+    "mtr_index_load_rows": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32]),
+    "mtr_index_create": (_i32, [_vp, _i64, _i32, _i32, _i32, _i32, _i32, _i64, _pp]),
+    "mtr_index_search": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "mtr_index_search_device": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "mtr_merge_topk_device": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
+    "mtr_index_info": (_i32, [_vp, C.POINTER(_i64), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32),
+                              C.POINTER(_i32), C.POINTER(_i64)]),
+    "mtr_index_read_rows": (_i32, [_vp, _i64, _i64, _vp]),
+    "mtr_index_profile": (_i32, [_vp, _i32]),
+    "mtr_index_scan_time": (_i32, [_vp, C.POINTER(_i32), C.POINTER(C.c_double)]),
+    "mtr_index_destroy": (None, [_vp]),
+    "mtr_last_error": (C.c_char_p, []),
+    "mtr_version": (C.c_char_p, []),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library; raises NativeLibraryError when it has not been built."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise NativeLibraryError(
+                        f"{LIB_PATH} is missing: build it with `make -C medical-rag_amd/csrc` "
+                        "(or python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+                handle = C.CDLL(LIB_PATH)
+                for name, (res, args) in SIGNATURES.items():
+                    fn = getattr(handle, name)
+                    fn.restype = res
+                    fn.argtypes = args
+                _lib = handle
+    return _lib
+
+
+def last_error() -> str:
+    msg = lib().mtr_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(rc: int) -> None:
+    """Maps a C return code to the exception the reference's callers expect:
+    non-finite input -> ValueError (what sklearn raises through
+    pipeline/utils/local_rag.py:77), everything else -> RuntimeError."""
+    if rc == MTR_OK:
+        return
+    msg = last_error()
+    if rc == MTR_ERR_NONFINITE:
+        raise ValueError(msg or "Input contains NaN or infinity.")
+    if rc == MTR_ERR_INVALID:
+        raise ValueError(f"medtutor_retrieval: {msg}")
+    if rc == MTR_ERR_OOM:
+        raise MemoryError(f"medtutor_retrieval: {msg}")
+    raise RuntimeError(f"medtutor_retrieval error {rc}: {msg}")
+
+
+def np_dtype_code(a: np.ndarray) -> int:
+    if a.dtype == np.float32:
+        return MTR_F32
+    if a.dtype == np.float64:
+        return MTR_F64
+    raise TypeError(f"unsupported array dtype {a.dtype}")
+
+
+def torch_dtype_code(t) -> int:
+    import torch
+    if t.dtype == torch.float32:
+        return MTR_F32
+    if t.dtype == torch.float64:
+        return MTR_F64
+    if t.dtype == torch.bfloat16:
+        return MTR_BF16
+    raise TypeError(f"unsupported tensor dtype {t.dtype}")
+
+
+def as_host_matrix(a, name="array") -> np.ndarray:
+    """C-contiguous float32/float64 2-D view of `a` (1-D becomes one row)."""
+    a = np.asarray(a)
+    if a.dtype not in (np.float32, np.float64):
+        a = a.astype(np.float64 if a.dtype.kind in "iu" or a.dtype.itemsize > 4 else np.float32)
+    if a.ndim == 1:
+        a = a[None, :]
+    if a.ndim != 2:
+        raise ValueError(f"{name} must be 1-D or 2-D, got shape {a.shape}")
+    return np.ascontiguousarray(a)
+
+
+class DeviceShard:
+    """One row shard resident in the HBM of one GPU (mtr_index_t*)."""
+
+    def __init__(self, handle, keepalive=None):
+        self._h = handle
+        self._keep = keepalive
+
+    # -- construction -------------------------------------------------------
+    @classmethod
+    def alloc(cls, n, d, store_dtype="fp32", normalize=True, device=0, row_offset=0):
+        out = C.c_void_p()
+        check(lib().mtr_index_alloc(int(n), int(d), STORE_DTYPES[store_dtype], int(bool(normalize)), int(device),
+                                    int(row_offset), C.byref(out)))
+        return cls(out)
+
+    @classmethod
+    def from_host(cls, rows, store_dtype="fp32", normalize=True, device=0, row_offset=0):
+        rows = as_host_matrix(rows, "rows")
+        out = C.c_void_p()
+        check(lib().mtr_index_create(rows.ctypes.data_as(C.c_void_p), rows.shape[0], rows.shape[1],
+                                     np_dtype_code(rows), STORE_DTYPES[store_dtype], int(bool(normalize)),
+                                     int(device), int(row_offset), C.byref(out)))
+        return cls(out)
+
+    def load_host(self, row_start, rows):
+        rows = as_host_matrix(rows, "rows")
+        if rows.shape[1] != self.d:
+            raise ValueError(f"rows have {rows.shape[1]} columns, shard has {self.d}")
+        check(lib().mtr_index_load_rows(self._h, int(row_start), rows.ctypes.data_as(C.c_void_p), rows.shape[0],
+                                        np_dtype_code(rows), 0))
+
+    def load_device(self, row_start, tensor):
+        """tensor: contiguous (rows, d) torch tensor on this shard's GPU."""
+        if tensor.dim() != 2 or tensor.shape[1] != self.d or not tensor.is_contiguous() or not tensor.is_cuda:
+            raise ValueError("load_device wants a contiguous (rows, d) tensor on the GPU")
+        import torch
+        torch.cuda.current_stream(tensor.device).synchronize()
+        check(lib().mtr_index_load_rows(self._h, int(row_start), C.c_void_p(tensor.data_ptr()), tensor.shape[0],
+                                        torch_dtype_code(tensor), 1))
+
+    # -- queries ------------------------------------------------------------
+    def info(self):
+        n, ro = _i64(), _i64()
+        d, dt, nm, dev = _i32(), _i32(), _i32(), _i32()
+        check(lib().mtr_index_info(self._h, C.byref(n), C.byref(d), C.byref(dt), C.byref(nm), C.byref(dev),
+                                   C.byref(ro)))
+        return {"n": n.value, "d": d.value, "store_dtype": "bf16" if dt.value == MTR_BF16 else "fp32",
+                "normalized": bool(nm.value), "device": dev.value, "row_offset": ro.value}
+
+    @property
+    def n(self):
+        return self.info()["n"]
+
+    @property
+    def d(self):
+        return self.info()["d"]
+
+    def search(self, queries, k=10, metric="cosine"):
+        """Host in, host out: (idx int64 (B, k), score float32 (B, k))."""
+        q = as_host_matrix(queries, "queries")
+        if q.shape[1] != self.d:
+            raise ValueError(f"queries have {q.shape[1]} columns, shard has {self.d}")
+        b = q.shape[0]
+        idx = np.empty((b, k), dtype=np.int64)
+        score = np.empty((b, k), dtype=np.float32)
+        check(lib().mtr_index_search(self._h, q.ctypes.data_as(C.c_void_p), np_dtype_code(q), 0, b, int(k),
+                                     METRICS[metric], idx.ctypes.data_as(C.c_void_p),
+                                     score.ctypes.data_as(C.c_void_p)))
+        return idx, score
+
+    def search_device(self, queries, k=10, metric="cosine", out=None, stream=None):
+        """Device in, device out (torch tensors on the shard's GPU), enqueued on
+        `stream` (a raw hipStream_t value; default: torch's current stream)
+        without synchronising."""
+        import torch
+        if queries.dim() == 1:
+            queries = queries[None, :]
+        if not queries.is_cuda or not queries.is_contiguous() or queries.shape[1] != self.d:
+            raise ValueError("search_device wants a contiguous (B, d) tensor on the GPU")
+        b = queries.shape[0]
+        if out is None:
+            idx = torch.empty((b, k), dtype=torch.int64, device=queries.device)
+            score = torch.empty((b, k), dtype=torch.float32, device=queries.device)
+        else:
+            idx, score = out
+        if stream is None:
+            stream = torch.cuda.current_stream(queries.device).cuda_stream
+        check(lib().mtr_index_search_device(self._h, C.c_void_p(queries.data_ptr()), torch_dtype_code(queries), b,
+                                            int(k), METRICS[metric], C.c_void_p(idx.data_ptr()),
+                                            C.c_void_p(score.data_ptr()), C.c_void_p(stream)))
+        return idx, score
+
+    def read_rows(self, row_start=0, n_rows=None):
+        inf = self.info()
+        if n_rows is None:
+            n_rows = inf["n"] - row_start
+        out = np.empty((n_rows, inf["d"]), dtype=np.float32)
+        check(lib().mtr_index_read_rows(self._h, int(row_start), int(n_rows), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def profile(self, enable=True):
+        check(lib().mtr_index_profile(self._h, int(bool(enable))))
+
+    def scan_time(self):
+        """(launch count, total milliseconds) of the scoring kernel since profile(True)."""
+        n, ms = _i32(), C.c_double()
+        check(lib().mtr_index_scan_time(self._h, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            lib().mtr_index_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def merge_topk_device(idx, score, k_out, stream=None):
+    """idx/score: (n_lists, B, k_in) int64 / float32 tensors on one GPU.
+    Returns (idx (B, k_out), score (B, k_out)) ordered by (score desc, id asc)."""
+    import torch
+    if idx.dim() != 3 or idx.shape != score.shape or not idx.is_cuda:
+        raise ValueError("merge_topk_device wants (n_lists, B, k_in) GPU tensors")
+    idx = idx.contiguous()
+    score = score.contiguous()
+    n_lists, b, k_in = idx.shape
+    out_i = torch.empty((b, k_out), dtype=torch.int64, device=idx.device)
+    out_s = torch.empty((b, k_out), dtype=torch.float32, device=idx.device)
+    if stream is None:
+        stream = torch.cuda.current_stream(idx.device).cuda_stream
+    check(lib().mtr_merge_topk_device(C.c_void_p(idx.data_ptr()), C.c_void_p(score.data_ptr()), n_lists, b, k_in,
+                                      int(k_out), C.c_void_p(out_i.data_ptr()), C.c_void_p(out_s.data_ptr()),
+                                      idx.device.index or 0, C.c_void_p(stream)))
+    return out_i, out_s

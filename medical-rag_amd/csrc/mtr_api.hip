@@ -1,0 +1,415 @@
+// C ABI of the retrieval library (declared in include/medtutor_retrieval.h):
+// shard handles, the row loader, search and candidate merge.  Host-side only;
+// the kernels are in scan_gemv.hip, merge_topk.hip and load_rows.hip.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/medtutor_retrieval.h"
+#include "mtr_device.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(e_ == hipErrorOutOfMemory ? MTR_ERR_OOM : MTR_ERR_HIP, "%s: %s", #expr, \
+                        hipGetErrorString(e_));                                            \
+    } while (0)
+
+int dtype_size(int dt) { return dt == MTR_F32 ? 4 : dt == MTR_F64 ? 8 : dt == MTR_BF16 ? 2 : 0; }
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return MTR_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = std::max(bytes, (size_t)4096);
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(e == hipErrorOutOfMemory ? MTR_ERR_OOM : MTR_ERR_HIP, "hipMalloc(%zu): %s", want,
+                        hipGetErrorString(e));
+        }
+        cap = want;
+        return MTR_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+}  // namespace
+
+struct mtr_index {
+    int device = 0;
+    int64_t n = 0;
+    int d = 0;
+    int ld = 0;  // stored row stride in elements
+    int dtype = MTR_F32;
+    int normalized = 0;
+    int64_t row_offset = 0;
+    int num_cus = 256;
+    void* rows = nullptr;
+    int* flag = nullptr;  // device word set by the loader on NaN/inf
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    DevBuf q_f32;      // padded fp32 queries of one pass
+    DevBuf q_in;       // staging for host queries
+    DevBuf cand_s, cand_i;
+    DevBuf out_i, out_s;
+    DevBuf stage;      // staging for host rows
+    void* pinned = nullptr;
+    size_t pinned_cap = 0;
+    // profiling
+    bool profiling = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    size_t events_used = 0;
+};
+
+namespace {
+
+constexpr size_t kStageBytes = 64u << 20;
+
+int check_index(const mtr_index* ix) {
+    if (!ix) return fail(MTR_ERR_INVALID, "index handle is NULL");
+    return MTR_OK;
+}
+
+// Scoring + merge of one batch, enqueued on `stream`.  dev_queries: b x d in
+// q_dtype on the shard's device.  check_flag: leave the loader's non-finite
+// flag set for the caller to read.
+int enqueue_search(mtr_index* ix, const void* dev_queries, int q_dtype, int b, int k, int metric,
+                   long long* dev_out_idx, float* dev_out_score, hipStream_t stream) {
+    if (metric == MTR_COSINE && !ix->normalized)
+        return fail(MTR_ERR_INVALID, "cosine search needs a shard built with normalize=1");
+    mtr::ScanPlan plan;
+    if (mtr::plan_scan(ix->dtype, ix->n, ix->d, ix->ld, b, k, ix->num_cus, &plan) != 0)
+        return fail(MTR_ERR_INVALID, "unsupported search shape (d=%d, k=%d)", ix->d, k);
+    int rc;
+    if ((rc = ix->q_f32.reserve((size_t)plan.qb * plan.qstride * 4)) != MTR_OK) return rc;
+    if ((rc = ix->cand_s.reserve((size_t)plan.qb * plan.grid * k * 4)) != MTR_OK) return rc;
+    if ((rc = ix->cand_i.reserve((size_t)plan.qb * plan.grid * k * 4)) != MTR_OK) return rc;
+    const int qsize = dtype_size(q_dtype);
+    for (int b0 = 0; b0 < b; b0 += plan.qb) {
+        const int nb = std::min(plan.qb, b - b0);
+        // Padded fp32 queries; unused query slots of the pass are zero.
+        HIP_TRY(hipMemsetAsync(ix->q_f32.p, 0, (size_t)plan.qb * plan.qstride * 4, stream));
+        HIP_TRY(mtr::launch_load_rows(static_cast<const char*>(dev_queries) + (size_t)b0 * ix->d * qsize, q_dtype, nb,
+                                      ix->d, ix->q_f32.p, MTR_F32, plan.qstride, metric == MTR_COSINE ? 1 : 0,
+                                      ix->flag, stream));
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (ix->profiling) {
+            if (ix->events_used == ix->events.size()) {
+                hipEvent_t a, c;
+                HIP_TRY(hipEventCreate(&a));
+                HIP_TRY(hipEventCreate(&c));
+                ix->events.emplace_back(a, c);
+            }
+            e0 = ix->events[ix->events_used].first;
+            e1 = ix->events[ix->events_used].second;
+            ix->events_used++;
+            HIP_TRY(hipEventRecord(e0, stream));
+        }
+        HIP_TRY(mtr::launch_scan_topk(ix->rows, ix->dtype, ix->n, ix->ld, ix->d, static_cast<const float*>(ix->q_f32.p),
+                                      k, plan, static_cast<float*>(ix->cand_s.p), static_cast<int*>(ix->cand_i.p),
+                                      stream));
+        if (ix->profiling) HIP_TRY(hipEventRecord(e1, stream));
+        HIP_TRY(mtr::launch_merge_topk(static_cast<const float*>(ix->cand_s.p), static_cast<const int*>(ix->cand_i.p),
+                                       nullptr, plan.grid, (long long)k, (long long)plan.grid * k, k, nb, k,
+                                       ix->row_offset, dev_out_idx + (size_t)b0 * k, dev_out_score + (size_t)b0 * k,
+                                       stream));
+    }
+    return MTR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* mtr_last_error(void) { return g_err.c_str(); }
+
+const char* mtr_version(void) { return "medtutor-retrieval-mi355x 0.1 (gfx950)"; }
+
+int mtr_index_alloc(int64_t n, int32_t d, int32_t store_dtype, int32_t normalize, int32_t device_id,
+                    int64_t row_offset, mtr_index_t** out) {
+    if (!out) return fail(MTR_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (n < 1 || d < 1) return fail(MTR_ERR_INVALID, "n and d must be positive (n=%lld, d=%d)", (long long)n, d);
+    if (n > 0x7fffffffll) return fail(MTR_ERR_INVALID, "a shard holds at most 2^31-1 rows");
+    if (store_dtype != MTR_F32 && store_dtype != MTR_BF16)
+        return fail(MTR_ERR_INVALID, "store_dtype must be MTR_F32 or MTR_BF16");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device_id < 0 || device_id >= ndev) return fail(MTR_ERR_INVALID, "device %d of %d", device_id, ndev);
+    DeviceGuard guard(device_id);
+    if (!guard.ok) return fail(MTR_ERR_HIP, "hipSetDevice(%d) failed", device_id);
+    mtr_index* ix = new (std::nothrow) mtr_index();
+    if (!ix) return fail(MTR_ERR_OOM, "host allocation failed");
+    ix->device = device_id;
+    ix->n = n;
+    ix->d = d;
+    ix->dtype = store_dtype;
+    ix->normalized = normalize ? 1 : 0;
+    ix->row_offset = row_offset;
+    const int epc = 16 / dtype_size(store_dtype);
+    ix->ld = (d + epc - 1) / epc * epc;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) ix->num_cus = prop.multiProcessorCount;
+    hipError_t e = hipMalloc(&ix->rows, (size_t)n * ix->ld * dtype_size(store_dtype));
+    if (e != hipSuccess) {
+        delete ix;
+        return fail(e == hipErrorOutOfMemory ? MTR_ERR_OOM : MTR_ERR_HIP, "hipMalloc of %lld x %d rows: %s",
+                    (long long)n, d, hipGetErrorString(e));
+    }
+    e = hipMalloc(reinterpret_cast<void**>(&ix->flag), 256);
+    if (e == hipSuccess) e = hipMemset(ix->flag, 0, 256);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        mtr_index_destroy(ix);
+        return fail(MTR_ERR_HIP, "shard set-up: %s", hipGetErrorString(e));
+    }
+    *out = ix;
+    return MTR_OK;
+}
+
+int mtr_index_load_rows(mtr_index_t* ix, int64_t row_start, const void* rows, int64_t n_rows, int32_t src_dtype,
+                        int32_t rows_on_device) {
+    int rc = check_index(ix);
+    if (rc != MTR_OK) return rc;
+    if (!rows && n_rows > 0) return fail(MTR_ERR_INVALID, "rows is NULL");
+    const int ssize = dtype_size(src_dtype);
+    if (!ssize) return fail(MTR_ERR_INVALID, "bad src_dtype %d", src_dtype);
+    if (row_start < 0 || n_rows < 0 || row_start + n_rows > ix->n)
+        return fail(MTR_ERR_INVALID, "rows [%lld, %lld) outside the shard of %lld rows", (long long)row_start,
+                    (long long)(row_start + n_rows), (long long)ix->n);
+    std::lock_guard<std::mutex> lock(ix->mu);
+    DeviceGuard guard(ix->device);
+    const size_t esize = dtype_size(ix->dtype);
+    const size_t src_row = (size_t)ix->d * ssize;
+    HIP_TRY(hipMemsetAsync(ix->flag, 0, 4, ix->stream));
+    if (rows_on_device) {
+        char* dst = static_cast<char*>(ix->rows) + (size_t)row_start * ix->ld * esize;
+        HIP_TRY(mtr::launch_load_rows(rows, src_dtype, n_rows, ix->d, dst, ix->dtype, ix->ld, ix->normalized, ix->flag,
+                                      ix->stream));
+    } else {
+        int64_t chunk_rows = std::max<int64_t>(1, (int64_t)(kStageBytes / src_row));
+        if ((rc = ix->stage.reserve((size_t)std::min(chunk_rows, n_rows) * src_row)) != MTR_OK) return rc;
+        for (int64_t r0 = 0; r0 < n_rows; r0 += chunk_rows) {
+            const int64_t nr = std::min(chunk_rows, n_rows - r0);
+            HIP_TRY(hipMemcpyAsync(ix->stage.p, static_cast<const char*>(rows) + (size_t)r0 * src_row,
+                                   (size_t)nr * src_row, hipMemcpyHostToDevice, ix->stream));
+            char* dst = static_cast<char*>(ix->rows) + (size_t)(row_start + r0) * ix->ld * esize;
+            HIP_TRY(mtr::launch_load_rows(ix->stage.p, src_dtype, nr, ix->d, dst, ix->dtype, ix->ld, ix->normalized,
+                                          ix->flag, ix->stream));
+            // the staging buffer is reused by the next chunk
+            HIP_TRY(hipStreamSynchronize(ix->stream));
+        }
+    }
+    int flag = 0;
+    HIP_TRY(hipMemcpyAsync(&flag, ix->flag, 4, hipMemcpyDeviceToHost, ix->stream));
+    HIP_TRY(hipStreamSynchronize(ix->stream));
+    if (flag) return fail(MTR_ERR_NONFINITE, "Input contains NaN or infinity.");
+    return MTR_OK;
+}
+
+int mtr_index_create(const void* host_rows, int64_t n, int32_t d, int32_t src_dtype, int32_t store_dtype,
+                     int32_t normalize, int32_t device_id, int64_t row_offset, mtr_index_t** out) {
+    int rc = mtr_index_alloc(n, d, store_dtype, normalize, device_id, row_offset, out);
+    if (rc != MTR_OK) return rc;
+    rc = mtr_index_load_rows(*out, 0, host_rows, n, src_dtype, 0);
+    if (rc != MTR_OK) {
+        std::string keep = g_err;
+        mtr_index_destroy(*out);
+        *out = nullptr;
+        g_err = keep;
+    }
+    return rc;
+}
+
+int mtr_index_search(mtr_index_t* ix, const void* queries, int32_t q_dtype, int32_t queries_on_device, int32_t b,
+                     int32_t k, int32_t metric, int64_t* out_idx, float* out_score) {
+    int rc = check_index(ix);
+    if (rc != MTR_OK) return rc;
+    if (!queries || !out_idx || !out_score) return fail(MTR_ERR_INVALID, "NULL argument");
+    if (b < 1) return fail(MTR_ERR_INVALID, "b must be >= 1");
+    if (k < 1 || k > MTR_MAX_K) return fail(MTR_ERR_INVALID, "k must be in [1, %d]", MTR_MAX_K);
+    if (metric != MTR_COSINE && metric != MTR_IP) return fail(MTR_ERR_INVALID, "bad metric %d", metric);
+    const int qsize = dtype_size(q_dtype);
+    if (!qsize) return fail(MTR_ERR_INVALID, "bad q_dtype %d", q_dtype);
+    std::lock_guard<std::mutex> lock(ix->mu);
+    DeviceGuard guard(ix->device);
+    const void* dq = queries;
+    if (!queries_on_device) {
+        const size_t bytes = (size_t)b * ix->d * qsize;
+        if ((rc = ix->q_in.reserve(bytes)) != MTR_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(ix->q_in.p, queries, bytes, hipMemcpyHostToDevice, ix->stream));
+        dq = ix->q_in.p;
+    }
+    if ((rc = ix->out_i.reserve((size_t)b * k * 8)) != MTR_OK) return rc;
+    if ((rc = ix->out_s.reserve((size_t)b * k * 4)) != MTR_OK) return rc;
+    HIP_TRY(hipMemsetAsync(ix->flag, 0, 4, ix->stream));
+    rc = enqueue_search(ix, dq, q_dtype, b, k, metric, static_cast<long long*>(ix->out_i.p),
+                        static_cast<float*>(ix->out_s.p), ix->stream);
+    if (rc != MTR_OK) {
+        (void)hipStreamSynchronize(ix->stream);
+        return rc;
+    }
+    int flag = 0;
+    HIP_TRY(hipMemcpyAsync(out_idx, ix->out_i.p, (size_t)b * k * 8, hipMemcpyDeviceToHost, ix->stream));
+    HIP_TRY(hipMemcpyAsync(out_score, ix->out_s.p, (size_t)b * k * 4, hipMemcpyDeviceToHost, ix->stream));
+    HIP_TRY(hipMemcpyAsync(&flag, ix->flag, 4, hipMemcpyDeviceToHost, ix->stream));
+    HIP_TRY(hipStreamSynchronize(ix->stream));
+    if (flag) return fail(MTR_ERR_NONFINITE, "Input contains NaN or infinity.");
+    return MTR_OK;
+}
+
+int mtr_index_search_device(mtr_index_t* ix, const void* dev_queries, int32_t q_dtype, int32_t b, int32_t k,
+                            int32_t metric, int64_t* dev_out_idx, float* dev_out_score, void* stream) {
+    int rc = check_index(ix);
+    if (rc != MTR_OK) return rc;
+    if (!dev_queries || !dev_out_idx || !dev_out_score) return fail(MTR_ERR_INVALID, "NULL argument");
+    if (b < 1) return fail(MTR_ERR_INVALID, "b must be >= 1");
+    if (k < 1 || k > MTR_MAX_K) return fail(MTR_ERR_INVALID, "k must be in [1, %d]", MTR_MAX_K);
+    if (metric != MTR_COSINE && metric != MTR_IP) return fail(MTR_ERR_INVALID, "bad metric %d", metric);
+    if (!dtype_size(q_dtype)) return fail(MTR_ERR_INVALID, "bad q_dtype %d", q_dtype);
+    std::lock_guard<std::mutex> lock(ix->mu);
+    DeviceGuard guard(ix->device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return enqueue_search(ix, dev_queries, q_dtype, b, k, metric, reinterpret_cast<long long*>(dev_out_idx),
+                          dev_out_score, s);
+}
+
+int mtr_merge_topk_device(const int64_t* dev_idx, const float* dev_score, int32_t n_lists, int32_t b, int32_t k_in,
+                          int32_t k_out, int64_t* dev_out_idx, float* dev_out_score, int32_t device_id,
+                          void* stream) {
+    if (!dev_idx || !dev_score || !dev_out_idx || !dev_out_score) return fail(MTR_ERR_INVALID, "NULL argument");
+    if (n_lists < 1 || b < 1 || k_in < 1 || k_out < 1 || k_out > MTR_MAX_K)
+        return fail(MTR_ERR_INVALID, "bad merge shape (lists=%d, b=%d, k_in=%d, k_out=%d)", n_lists, b, k_in, k_out);
+    DeviceGuard guard(device_id);
+    if (!guard.ok) return fail(MTR_ERR_HIP, "hipSetDevice(%d) failed", device_id);
+    HIP_TRY(mtr::launch_merge_topk(dev_score, nullptr, reinterpret_cast<const long long*>(dev_idx), n_lists,
+                                   (long long)b * k_in, (long long)k_in, k_in, b, k_out, 0,
+                                   reinterpret_cast<long long*>(dev_out_idx), dev_out_score,
+                                   static_cast<hipStream_t>(stream)));
+    return MTR_OK;
+}
+
+int mtr_index_info(const mtr_index_t* ix, int64_t* n, int32_t* d, int32_t* store_dtype, int32_t* normalized,
+                   int32_t* device_id, int64_t* row_offset) {
+    int rc = check_index(ix);
+    if (rc != MTR_OK) return rc;
+    if (n) *n = ix->n;
+    if (d) *d = ix->d;
+    if (store_dtype) *store_dtype = ix->dtype;
+    if (normalized) *normalized = ix->normalized;
+    if (device_id) *device_id = ix->device;
+    if (row_offset) *row_offset = ix->row_offset;
+    return MTR_OK;
+}
+
+int mtr_index_read_rows(mtr_index_t* ix, int64_t row_start, int64_t n_rows, float* host_out) {
+    int rc = check_index(ix);
+    if (rc != MTR_OK) return rc;
+    if (!host_out || row_start < 0 || n_rows < 0 || row_start + n_rows > ix->n)
+        return fail(MTR_ERR_INVALID, "bad row range");
+    if (n_rows == 0) return MTR_OK;
+    std::lock_guard<std::mutex> lock(ix->mu);
+    DeviceGuard guard(ix->device);
+    const size_t bytes = (size_t)n_rows * ix->d * 4;
+    if ((rc = ix->stage.reserve(bytes)) != MTR_OK) return rc;
+    const char* src = static_cast<const char*>(ix->rows) + (size_t)row_start * ix->ld * dtype_size(ix->dtype);
+    HIP_TRY(mtr::launch_read_rows(src, ix->dtype, n_rows, ix->d, ix->ld, static_cast<float*>(ix->stage.p), ix->stream));
+    HIP_TRY(hipMemcpyAsync(host_out, ix->stage.p, bytes, hipMemcpyDeviceToHost, ix->stream));
+    HIP_TRY(hipStreamSynchronize(ix->stream));
+    return MTR_OK;
+}
+
+int mtr_index_profile(mtr_index_t* ix, int32_t enable) {
+    int rc = check_index(ix);
+    if (rc != MTR_OK) return rc;
+    std::lock_guard<std::mutex> lock(ix->mu);
+    ix->profiling = enable != 0;
+    ix->events_used = 0;
+    return MTR_OK;
+}
+
+int mtr_index_scan_time(mtr_index_t* ix, int32_t* n_launches, double* total_ms) {
+    int rc = check_index(ix);
+    if (rc != MTR_OK) return rc;
+    std::lock_guard<std::mutex> lock(ix->mu);
+    DeviceGuard guard(ix->device);
+    double sum = 0.0;
+    for (size_t i = 0; i < ix->events_used; ++i) {
+        HIP_TRY(hipEventSynchronize(ix->events[i].second));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ix->events[i].first, ix->events[i].second));
+        sum += ms;
+    }
+    if (n_launches) *n_launches = (int32_t)ix->events_used;
+    if (total_ms) *total_ms = sum;
+    return MTR_OK;
+}
+
+void mtr_index_destroy(mtr_index_t* ix) {
+    if (!ix) return;
+    {
+        DeviceGuard guard(ix->device);
+        if (ix->stream) (void)hipStreamSynchronize(ix->stream);
+        for (auto& ev : ix->events) {
+            (void)hipEventDestroy(ev.first);
+            (void)hipEventDestroy(ev.second);
+        }
+        ix->q_f32.release();
+        ix->q_in.release();
+        ix->cand_s.release();
+        ix->cand_i.release();
+        ix->out_i.release();
+        ix->out_s.release();
+        ix->stage.release();
+        if (ix->flag) (void)hipFree(ix->flag);
+        if (ix->rows) (void)hipFree(ix->rows);
+        if (ix->stream) (void)hipStreamDestroy(ix->stream);
+    }
+    delete ix;
+}
+
+}  // extern "C"

@@ -1,0 +1,83 @@
+// Shared device-side helpers and kernel launch prototypes for the retrieval library.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mtr {
+
+typedef unsigned short bf16_t;  // raw bfloat16 bits
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float(((unsigned int)h) << 16); }
+
+// Round-to-nearest-even; callers guarantee a finite input (non-finite inputs
+// are rejected before any conversion).
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    unsigned int u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+// Elements per 16-byte chunk and chunk -> float unpacking for the two storage types.
+template <typename T> struct Chunk;
+template <> struct Chunk<float> {
+    static constexpr int EPC = 4;
+    static __device__ __forceinline__ void unpack(const u32x4& v, float (&f)[4]) {
+        f[0] = __uint_as_float(v[0]); f[1] = __uint_as_float(v[1]);
+        f[2] = __uint_as_float(v[2]); f[3] = __uint_as_float(v[3]);
+    }
+};
+template <> struct Chunk<bf16_t> {
+    static constexpr int EPC = 8;
+    static __device__ __forceinline__ void unpack(const u32x4& v, float (&f)[8]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f[2 * i] = __uint_as_float(v[i] << 16);
+            f[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
+        }
+    }
+};
+
+// ---- host-callable launchers (defined in the .hip files) -------------------
+
+// Row loader: finiteness check, optional L2 normalisation (float64 norm; norms
+// below 10*DBL_EPSILON count as 1), cast to the storage type, zero padding of
+// columns [d, ld).  src_dtype / dst_dtype use the MTR_F32/F64/BF16 codes.
+hipError_t launch_load_rows(const void* src, int src_dtype, int64_t n_rows, int d, void* dst,
+                            int dst_dtype, int ld, int normalize, int* nonfinite_flag,
+                            hipStream_t stream);
+
+// Copies stored rows back as fp32 (n_rows x d).
+hipError_t launch_read_rows(const void* rows, int dtype, int64_t n_rows, int d, int ld, float* dst,
+                            hipStream_t stream);
+
+struct ScanPlan {
+    int qb;          // queries per pass (1, 2, 4 or 8)
+    int nit;         // 64-lane sweeps per row
+    int qstride;     // floats per padded query
+    int grid;        // workgroups
+    size_t lds;      // dynamic LDS bytes
+    int nontemporal; // stream rows past the caches
+};
+
+// Chooses the pass width and launch shape for the row scan.
+int plan_scan(int dtype, int64_t n, int d, int ld, int b, int k, int num_cus, ScanPlan* plan);
+
+// Row scan + fused per-workgroup top-k.  q: plan.qb padded fp32 queries
+// ([qb][qstride]); outputs [qb][grid][k] candidate (score, local row) lists,
+// each sorted, padded with (-inf, -1).
+hipError_t launch_scan_topk(const void* rows, int dtype, int64_t n, int ld, int d, const float* q,
+                            int k, const ScanPlan& plan, float* cand_s, int* cand_i,
+                            hipStream_t stream);
+
+// Candidate merge: for each of b queries, the best k_out of n_lists * k_in
+// candidates.  Candidate (list l, query q, slot j) sits at
+// l*list_stride + q*query_stride + j.  idx32 != NULL: 32-bit local rows, to
+// which idx_offset is added; else idx64.  Entries with id < 0 are padding.
+hipError_t launch_merge_topk(const float* cand_s, const int* idx32, const long long* idx64,
+                             int n_lists, long long list_stride, long long query_stride, int k_in,
+                             int b, int k_out, long long idx_offset, long long* out_idx,
+                             float* out_score, hipStream_t stream);
+
+}  // namespace mtr

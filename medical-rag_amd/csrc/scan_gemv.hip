@@ -1,0 +1,293 @@
+// Row scan for small query batches: an HBM-bound sweep over the stored rows
+// with the top-k selection fused in, so no score row is ever written.
+//
+// Replaces the per-query work of retrieve_top_index
+// (pipeline/utils/local_rag.py:76-78): the float64 matrix rebuild, sklearn's
+// re-normalisation of all rows, the dgemv and the argmax.
+//
+// Layout of the work
+//   - A wave owns groups of R consecutive rows (grid-strided, so a wave sees
+//     its rows in increasing order).  For each 64-lane sweep `it` of a row,
+//     lane l loads the 16-byte chunk  it*64 + l  of each of the R rows straight
+//     into registers (one coalesced 1 KiB wave-load per row and sweep, R loads
+//     in flight per wave, no LDS round trip for the rows).
+//   - The QB queries of the pass live in LDS as zero-padded fp32; a lane reads
+//     the chunk that matches its row chunk, so chunks past the end of a row
+//     multiply by zero instead of being masked.
+//   - Each lane accumulates R*QB partial dot products; a butterfly exchange
+//     (halve the values, double the lanes summed) leaves every (row, query)
+//     total on its own lane after about R*QB cross-lane moves.
+//   - Totals go to the wave's per-query top-k lists (wave_topk.h); the four
+//     waves of a workgroup merge their lists at the end and the workgroup
+//     writes one sorted candidate list per query.
+//
+// Algorithmic bytes per launch: n * ld * sizeof(T) (each stored row byte is
+// read once); the query and candidate traffic is negligible beside it.
+#include "mtr_device.h"
+#include "wave_topk.h"
+
+namespace mtr {
+
+namespace {
+
+constexpr int kWaves = 4;  // waves per workgroup
+// Rows per wave group: 8 for one or two queries, 4 beyond (register budget).
+constexpr int rows_per_group(int qb) { return qb <= 2 ? 8 : 4; }
+
+template <bool NT>
+__device__ __forceinline__ u32x4 load_chunk(const u32x4* p) {
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+
+template <int V>
+struct Log2 { static constexpr int value = 1 + Log2<V / 2>::value; };
+template <>
+struct Log2<1> { static constexpr int value = 0; };
+
+// After the call, lane l holds in vals[0] the sum over all 64 lanes of the
+// value whose index is  l >> (6 - log2 V).
+template <int V>
+__device__ __forceinline__ void butterfly_reduce(float (&vals)[V], int lane) {
+    constexpr int LOGV = Log2<V>::value;
+#pragma unroll
+    for (int s = 0; s < LOGV; ++s) {
+        const int mask = 32 >> s;
+        const int half = V >> (s + 1);
+        const bool upper = (lane & mask) != 0;
+#pragma unroll
+        for (int j = 0; j < half; ++j) {
+            const float keep = upper ? vals[j + half] : vals[j];
+            const float send = upper ? vals[j] : vals[j + half];
+            vals[j] = keep + __shfl_xor(send, mask, 64);
+        }
+    }
+#pragma unroll
+    for (int m = (32 >> LOGV); m >= 1; m >>= 1) vals[0] += __shfl_xor(vals[0], m, 64);
+}
+
+struct ScanArgs {
+    const char* rows;
+    long long n;
+    long long row_bytes;
+    int nchunks;   // 16-byte chunks per row that hold data
+    int nit;       // sweeps per row = ceil(nchunks / 64)
+    const float* q;
+    int qstride;   // floats per padded query = nit * 64 * EPC
+    int k;
+    float* cand_s; // [QB][gridDim.x][k]
+    int* cand_i;
+};
+
+template <typename T, int QB, bool NT>
+__global__ __launch_bounds__(kWaves * 64) void scan_topk_kernel(ScanArgs a) {
+    constexpr int EPC = Chunk<T>::EPC;
+    constexpr int R = rows_per_group(QB);
+    constexpr int V = R * QB;
+    constexpr int LOGV = Log2<V>::value;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* q_lds = reinterpret_cast<float*>(smem);
+    float* list_s = q_lds + (size_t)QB * a.qstride;
+    int* list_i = reinterpret_cast<int*>(list_s + kWaves * QB * a.k);
+    int* cnt_lds = list_i + kWaves * QB * a.k;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+
+    {
+        const int n4 = QB * a.qstride / 4;
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.q);
+        f32x4* dst = reinterpret_cast<f32x4*>(q_lds);
+        for (int i = tid; i < n4; i += kWaves * 64) dst[i] = src[i];
+    }
+    __syncthreads();
+
+    WaveTopK<int> tk[QB];
+#pragma unroll
+    for (int b = 0; b < QB; ++b) tk[b].init(list_s + (wave * QB + b) * a.k, list_i + (wave * QB + b) * a.k, a.k);
+
+    const long long ngroups = (a.n + R - 1) / R;
+    const long long gstride = (long long)gridDim.x * kWaves;
+    const int vidx = lane >> (6 - LOGV);
+    const int my_r = vidx / QB;
+    const int my_b = vidx % QB;
+    const bool owner = (lane & ((1 << (6 - LOGV)) - 1)) == 0;
+
+    for (long long g = (long long)blockIdx.x * kWaves + wave; g < ngroups; g += gstride) {
+        const long long row0 = g * R;
+        const char* rp[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            long long row = row0 + r;
+            row = row < a.n ? row : a.n - 1;
+            rp[r] = a.rows + row * a.row_bytes;
+        }
+        float acc[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) acc[v] = 0.f;
+
+        for (int it = 0; it < a.nit; ++it) {
+            const int chunk = it * 64 + lane;
+            // Chunks past the row's data read chunk 0 instead (always in
+            // bounds); their query values are zero.
+            const int chunk_c = chunk < a.nchunks ? chunk : 0;
+            u32x4 raw[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                raw[r] = load_chunk<NT>(reinterpret_cast<const u32x4*>(rp[r] + (size_t)chunk_c * 16));
+            float qv[QB][EPC];
+#pragma unroll
+            for (int b = 0; b < QB; ++b) {
+                const f32x4* qp = reinterpret_cast<const f32x4*>(q_lds + (size_t)b * a.qstride + (size_t)chunk * EPC);
+#pragma unroll
+                for (int e4 = 0; e4 < EPC / 4; ++e4) {
+                    const f32x4 t = qp[e4];
+                    qv[b][4 * e4 + 0] = t[0]; qv[b][4 * e4 + 1] = t[1];
+                    qv[b][4 * e4 + 2] = t[2]; qv[b][4 * e4 + 3] = t[3];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float f[EPC];
+                Chunk<T>::unpack(raw[r], f);
+#pragma unroll
+                for (int b = 0; b < QB; ++b) {
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) acc[r * QB + b] = __builtin_fmaf(f[e], qv[b][e], acc[r * QB + b]);
+                }
+            }
+        }
+
+        butterfly_reduce<V>(acc, lane);
+        const float total = acc[0];
+        const long long row = row0 + my_r;
+        const bool valid = owner && row < a.n;
+#pragma unroll
+        for (int b = 0; b < QB; ++b) tk[b].push(total, (int)row, valid && my_b == b);
+    }
+
+    // Merge the four waves' lists into wave 0's and write the workgroup's lists.
+    if (lane == 0) {
+#pragma unroll
+        for (int b = 0; b < QB; ++b) cnt_lds[wave * QB + b] = tk[b].cnt;
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int b = 0; b < QB; ++b) {
+            for (int w = 1; w < kWaves; ++w) {
+                const int c = cnt_lds[w * QB + b];
+                const float* ws = list_s + (w * QB + b) * a.k;
+                const int* wi = list_i + (w * QB + b) * a.k;
+                for (int j0 = 0; j0 < c; j0 += 64) {
+                    const int j = j0 + lane;
+                    const bool ok = j < c;
+                    const float s = ok ? ws[j] : 0.f;
+                    const int i = ok ? wi[j] : 0;
+                    tk[b].push(s, i, ok);
+                }
+            }
+            float* os = a.cand_s + ((size_t)b * gridDim.x + blockIdx.x) * a.k;
+            int* oi = a.cand_i + ((size_t)b * gridDim.x + blockIdx.x) * a.k;
+            for (int j = lane; j < a.k; j += 64) {
+                const bool ok = j < tk[b].cnt;
+                os[j] = ok ? tk[b].ls[j] : -__builtin_huge_valf();
+                oi[j] = ok ? tk[b].li[j] : -1;
+            }
+        }
+    }
+}
+
+size_t scan_lds_bytes(int qb, int qstride, int k) {
+    return (size_t)qb * qstride * 4 + (size_t)kWaves * qb * k * 8 + (size_t)kWaves * qb * 4;
+}
+
+template <typename T, int QB, bool NT>
+hipError_t launch_one(const ScanArgs& a, const ScanPlan& plan, hipStream_t stream) {
+    hipLaunchKernelGGL((scan_topk_kernel<T, QB, NT>), dim3(plan.grid), dim3(kWaves * 64), plan.lds, stream, a);
+    return hipGetLastError();
+}
+
+template <typename T, int QB, bool NT>
+int occupancy_of(size_t lds) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, scan_topk_kernel<T, QB, NT>, kWaves * 64, lds) != hipSuccess)
+        nb = 1;
+    return nb < 1 ? 1 : nb;
+}
+
+template <typename T, bool NT>
+int occupancy_qb(int qb, size_t lds) {
+    switch (qb) {
+        case 1: return occupancy_of<T, 1, NT>(lds);
+        case 2: return occupancy_of<T, 2, NT>(lds);
+        case 4: return occupancy_of<T, 4, NT>(lds);
+        default: return occupancy_of<T, 8, NT>(lds);
+    }
+}
+
+template <typename T, bool NT>
+hipError_t launch_qb(const ScanArgs& a, const ScanPlan& plan, hipStream_t stream) {
+    switch (plan.qb) {
+        case 1: return launch_one<T, 1, NT>(a, plan, stream);
+        case 2: return launch_one<T, 2, NT>(a, plan, stream);
+        case 4: return launch_one<T, 4, NT>(a, plan, stream);
+        case 8: return launch_one<T, 8, NT>(a, plan, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace
+
+int plan_scan(int dtype, int64_t n, int d, int ld, int b, int k, int num_cus, ScanPlan* plan) {
+    const int esize = dtype == 0 ? 4 : 2;
+    const int epc = 16 / esize;
+    if ((ld * esize) % 16 != 0 || ld < d || k < 1 || n < 1 || b < 1) return -1;
+    const int nchunks = (d * esize + 15) / 16;
+    plan->nit = (nchunks + 63) / 64;
+    plan->qstride = plan->nit * 64 * epc;
+    int qb = 1;
+    while (qb < b && qb < 8) qb *= 2;
+    constexpr size_t kLdsBudget = 64 * 1024;
+    while (qb > 1 && scan_lds_bytes(qb, plan->qstride, k) > kLdsBudget) qb /= 2;
+    if (scan_lds_bytes(qb, plan->qstride, k) > kLdsBudget) return -1;
+    plan->qb = qb;
+    plan->lds = scan_lds_bytes(qb, plan->qstride, k);
+    // Rows larger than the Infinity Cache gain nothing from being cached.
+    plan->nontemporal = ((double)n * ld * esize > 192.0 * 1024 * 1024) ? 1 : 0;
+    int occ;
+    if (dtype == 0)
+        occ = plan->nontemporal ? occupancy_qb<float, true>(qb, plan->lds) : occupancy_qb<float, false>(qb, plan->lds);
+    else
+        occ = plan->nontemporal ? occupancy_qb<bf16_t, true>(qb, plan->lds) : occupancy_qb<bf16_t, false>(qb, plan->lds);
+    const int rpg = rows_per_group(qb);
+    const long long ngroups = (n + rpg - 1) / rpg;
+    long long want = (ngroups + kWaves - 1) / kWaves;
+    const long long cap = (long long)num_cus * occ;
+    plan->grid = (int)(want < cap ? want : cap);
+    if (plan->grid < 1) plan->grid = 1;
+    return 0;
+}
+
+hipError_t launch_scan_topk(const void* rows, int dtype, int64_t n, int ld, int d, const float* q, int k,
+                            const ScanPlan& plan, float* cand_s, int* cand_i, hipStream_t stream) {
+    const int esize = dtype == 0 ? 4 : 2;
+    ScanArgs a;
+    a.rows = static_cast<const char*>(rows);
+    a.n = n;
+    a.row_bytes = (long long)ld * esize;
+    a.nchunks = (d * esize + 15) / 16;
+    a.nit = plan.nit;
+    a.q = q;
+    a.qstride = plan.qstride;
+    a.k = k;
+    a.cand_s = cand_s;
+    a.cand_i = cand_i;
+    if (dtype == 0)
+        return plan.nontemporal ? launch_qb<float, true>(a, plan, stream) : launch_qb<float, false>(a, plan, stream);
+    return plan.nontemporal ? launch_qb<bf16_t, true>(a, plan, stream) : launch_qb<bf16_t, false>(a, plan, stream);
+}
+
+}  // namespace mtr

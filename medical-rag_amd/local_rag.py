@@ -1,0 +1,247 @@
+"""MI355X-native local dense retriever with the reference's call surface.
+
+Mirrors pipeline/utils/local_rag.py of yale-nlp/medical-rag: the same four
+functions with the same argument meaning and failure conventions, so
+`from utils.local_rag import ...` in pipeline/async_main.py:19 and
+pipeline/utils/retrieval.py:6 can be pointed here unchanged.  What differs is
+where the work happens: the page matrix is uploaded once into HBM as
+L2-normalised fp32/bf16 rows, and scoring + top-k run in hand-written HIP
+kernels behind the C ABI of include/medtutor_retrieval.h.  There is no CPU
+scoring path: without the native library or a GPU these functions raise.
+
+    load_embeddings(path)                      -> PageIndex (a Sequence of page dicts)   local_rag.py:90-101
+    embed_queries(queries, model, device, bs)  -> list[np.ndarray]                       local_rag.py:39-69
+    retrieve_top_index(query_emb, pages)       -> int (list position)                    local_rag.py:71-78
+    get_surrounding_pages(idx, pages, window)  -> list[dict]                             local_rag.py:80-88
+    search(pages, Q, k, metric)                -> (idx (B,k) int64, score (B,k) f32)     batched top-k extension
+"""
+from __future__ import annotations
+
+import json
+import logging
+import os
+from collections.abc import Sequence
+from pathlib import Path
+
+import numpy as np
+
+from . import _native
+
+__all__ = ["PageIndex", "load_embeddings", "embed_queries", "retrieve_top_index", "get_surrounding_pages", "search",
+           "configure"]
+
+_SETTINGS = {
+    "device": int(os.environ.get("MEDTUTOR_RETRIEVAL_DEVICE", os.environ.get("LOCAL_RANK", "0")) or 0),
+    "store_dtype": os.environ.get("MEDTUTOR_RETRIEVAL_DTYPE", "fp32"),
+}
+
+
+def configure(device: int | None = None, store_dtype: str | None = None) -> dict:
+    """Sets the GPU and storage type ("fp32" or "bf16") used for indexes built
+    after this call.  Mirrors the optional config keys `local_retriever_devices`
+    / `local_index_dtype`; defaults keep fp32 on GPU 0."""
+    if device is not None:
+        _SETTINGS["device"] = int(device)
+    if store_dtype is not None:
+        if store_dtype not in _native.STORE_DTYPES:
+            raise ValueError(f"store_dtype must be one of {sorted(_native.STORE_DTYPES)}")
+        _SETTINGS["store_dtype"] = store_dtype
+    return dict(_SETTINGS)
+
+
+class PageIndex(Sequence):
+    """The loaded index: behaves as the list of page dicts the reference's
+    callers expect (len, truthiness, [i], slicing, items with .items()) and
+    owns the device-resident embedding matrix.
+
+    Page dicts keep every key of the index file except "embedding" -- the
+    vectors live in HBM, in file order, so list position == device row.
+    """
+
+    def __init__(self, pages_meta: list, shard: "_native.DeviceShard"):
+        self._pages = pages_meta
+        self._shard = shard
+
+    @classmethod
+    def from_pages(cls, pages: list, device: int | None = None, store_dtype: str | None = None):
+        """pages: list of dicts with an "embedding" list each (the schema
+        written at pipeline/utils/embed.py:74-79)."""
+        if not pages:
+            raise ValueError("cannot build a PageIndex from no pages")
+        mat = np.array([p["embedding"] for p in pages], dtype=np.float64)
+        if mat.ndim != 2:
+            raise ValueError("page embeddings must all have the same length")
+        meta = [{k: v for k, v in p.items() if k != "embedding"} for p in pages]
+        return cls.from_matrix(mat, meta, device=device, store_dtype=store_dtype)
+
+    @classmethod
+    def from_matrix(cls, matrix, pages_meta: list | None = None, device: int | None = None,
+                    store_dtype: str | None = None, normalize: bool = True):
+        matrix = _native.as_host_matrix(matrix, "matrix")
+        if pages_meta is None:
+            pages_meta = [{"index": i, "text": ""} for i in range(matrix.shape[0])]
+        if len(pages_meta) != matrix.shape[0]:
+            raise ValueError("one page dict per matrix row is required")
+        shard = _native.DeviceShard.from_host(
+            matrix, store_dtype=store_dtype or _SETTINGS["store_dtype"], normalize=normalize,
+            device=_SETTINGS["device"] if device is None else device)
+        return cls(pages_meta, shard)
+
+    # -- Sequence protocol ----------------------------------------------------
+    def __len__(self):
+        return len(self._pages)
+
+    def __getitem__(self, i):
+        return self._pages[i]
+
+    def __bool__(self):
+        return len(self._pages) > 0
+
+    # -- search -----------------------------------------------------------------
+    @property
+    def shard(self):
+        return self._shard
+
+    def search(self, queries, k: int = 10, metric: str = "cosine"):
+        """Exact top-k: (idx (B, k) int64 list positions, score (B, k) float32),
+        rows ordered by (score desc, position asc); idx[:, 0] is what
+        retrieve_top_index returns for each query."""
+        return self._shard.search(queries, k=k, metric=metric)
+
+    def top1(self, query_embedding) -> int:
+        idx, _ = self._shard.search(query_embedding, k=1, metric="cosine")
+        return int(idx[0, 0])
+
+    def close(self):
+        self._shard.close()
+
+
+# Plain page lists handed to retrieve_top_index are uploaded once and reused
+# while they keep their length; at most _UPLOADED_MAX such uploads are kept.
+_UPLOADED: dict = {}
+_UPLOADED_MAX = 2
+
+
+def _index_for(page_embeddings) -> PageIndex:
+    if isinstance(page_embeddings, PageIndex):
+        return page_embeddings
+    key = id(page_embeddings)
+    hit = _UPLOADED.get(key)
+    # The entry keeps the container alive, so its id cannot be reused by another object.
+    if hit is not None and hit[0] is page_embeddings and hit[1] == len(page_embeddings):
+        return hit[2]
+    if isinstance(page_embeddings, np.ndarray):
+        index = PageIndex.from_matrix(page_embeddings)
+    else:
+        index = PageIndex.from_pages(list(page_embeddings))
+    while len(_UPLOADED) >= _UPLOADED_MAX:
+        _UPLOADED.pop(next(iter(_UPLOADED)))[2].close()
+    _UPLOADED[key] = (page_embeddings, len(page_embeddings), index)
+    return index
+
+
+def load_embeddings(path: str):
+    """Loads the page index written by pipeline/utils/embed.py:110-113 and puts
+    its vectors into HBM.  Missing file or undecodable JSON -> [] plus an error
+    log line, as pipeline/utils/local_rag.py:93-95,99-101 do; a missing native
+    library or GPU raises instead of degrading."""
+    path_obj = Path(path)
+    if not path_obj.exists():
+        logging.error(f"Embedding file not found: {path_obj}")
+        return []
+    try:
+        with open(path_obj, "r", encoding="utf-8") as f:
+            pages = json.load(f)
+    except json.JSONDecodeError:
+        logging.error(f"Error decoding JSON from embedding file: {path_obj}")
+        return []
+    if not pages:
+        return pages
+    index = PageIndex.from_pages(pages)
+    logging.info(f"Loaded {len(index)} page embeddings (d={index.shard.d}) into HBM on GPU {index.shard.info()['device']}")
+    return index
+
+
+def retrieve_top_index(query_embedding: np.ndarray, page_embeddings) -> int:
+    """List position of the page most cosine-similar to the query
+    (pipeline/utils/local_rag.py:71-78).  Empty query or no pages -> 0;
+    NaN/inf anywhere -> ValueError (what sklearn raises there)."""
+    query_embedding = np.asarray(query_embedding)
+    if query_embedding.size == 0 or len(page_embeddings) == 0:
+        return 0
+    return _index_for(page_embeddings).top1(query_embedding.reshape(1, -1))
+
+
+def get_surrounding_pages(target_index: int, all_pages, window_size: int = 1) -> list:
+    """The hit page and its neighbours, without their vectors
+    (pipeline/utils/local_rag.py:80-88)."""
+    n = len(all_pages)
+    if n == 0 or not (0 <= target_index < n):
+        return []
+    first = max(0, target_index - window_size)
+    last = min(n, target_index + window_size + 1)
+    return [{key: val for key, val in all_pages[i].items() if key != "embedding"} for i in range(first, last)]
+
+
+def search(page_embeddings, queries, k: int = 10, metric: str = "cosine"):
+    """Batched exact top-k over a loaded index (or a plain page list / matrix,
+    uploaded on first use)."""
+    return _index_for(page_embeddings).search(queries, k=k, metric=metric)
+
+
+# ---------------------------------------------------------------------------
+# Query encoder: stays a PyTorch(-ROCm) forward, as in the reference.
+# ---------------------------------------------------------------------------
+_ENCODER = {"key": None, "model": None, "tokenizer": None}
+
+
+def _encoder_for(model_name: str, device: str):
+    key = (model_name, device)
+    if _ENCODER["key"] == key:
+        return _ENCODER["model"], _ENCODER["tokenizer"]
+    # transformers/torch are imported only here so that the parent process does
+    # not initialise a GPU before its workers spawn (pipeline/utils/local_rag.py:15).
+    from transformers import AutoModel, AutoTokenizer
+    logging.info(f"Loading query embedding model '{model_name}' onto device '{device}'.")
+    try:
+        tok = AutoTokenizer.from_pretrained(model_name)
+        model = AutoModel.from_pretrained(model_name).to(device).eval()
+        if tok.pad_token is None:
+            tok.pad_token = tok.eos_token
+    except Exception as exc:  # same soft-fail as local_rag.py:34-37
+        logging.error(f"Failed to load query embedding model '{model_name}': {exc}", exc_info=True)
+        _ENCODER.update(key=None, model=None, tokenizer=None)
+        return None, None
+    _ENCODER.update(key=key, model=model, tokenizer=tok)
+    return model, tok
+
+
+def pool_and_normalize(last_hidden_state, attention_mask):
+    """Masked mean over tokens then L2 normalisation, the arithmetic of
+    pipeline/utils/local_rag.py:58-65 (torch tensors in, (B, d) tensor out)."""
+    import torch
+    mask = attention_mask.to(last_hidden_state.dtype).unsqueeze(-1)
+    summed = (last_hidden_state * mask).sum(dim=1)
+    counts = mask.sum(dim=1).clamp(min=1e-9)
+    return torch.nn.functional.normalize(summed / counts, p=2, dim=1)
+
+
+def embed_queries(queries: list, model_name: str, device: str, batch_size: int = 64) -> list:
+    """One float32 (d,) vector per query text (pipeline/utils/local_rag.py:39-69):
+    batches of `batch_size`, truncation at 512 tokens, masked mean pooling, L2
+    normalisation.  [] for no queries; empty arrays when the model cannot load."""
+    if not queries:
+        return []
+    model, tok = _encoder_for(model_name, device)
+    if model is None or tok is None:
+        return [np.array([]) for _ in queries]
+    import torch
+    vectors = []
+    with torch.no_grad():
+        for start in range(0, len(queries), batch_size):
+            enc = tok(queries[start:start + batch_size], padding=True, truncation=True, max_length=512,
+                      return_tensors="pt").to(device)
+            hidden = model(**enc).last_hidden_state
+            pooled = pool_and_normalize(hidden, enc["attention_mask"])
+            vectors.extend(v.cpu().numpy() for v in pooled.float())
+    return vectors
