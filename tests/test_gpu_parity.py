@@ -181,7 +181,12 @@ def test_random_shapes(rag, store, n, d, b, k):
     index = rag.PageIndex.from_matrix(corpus, store_dtype=store)
     idx, score = index.search(queries, k=k)
     s64 = orc.scores(queries, corpus)
-    check_topk(idx, score, s64, k, TOL[store], exact_idx=False)
+    tol = TOL[store]
+    if store == "bf16" and d < 64:
+        # bf16 keeps 8 significant bits: |score error| <= 2^-9 * sum|p_i q_i| <= 2^-9 for unit
+        # vectors, which only averages down below 1e-3 once d is a few dozen.
+        tol = 2.0 ** -8
+    check_topk(idx, score, s64, k, tol, exact_idx=False)
     if store == "fp32" and n > 10:
         # the duplicate pair ties bit-exactly: the lower row must come first
         for r in range(b):
