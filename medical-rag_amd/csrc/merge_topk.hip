@@ -8,7 +8,9 @@
 //
 // One workgroup per query.  Each wave streams a strided slice of the
 // candidates through its own top-k list (wave_topk.h), then wave 0 folds the
-// other waves' lists into its own and writes the result.
+// other waves' lists into its own and writes the result.  Every input list is
+// sorted (both producers write sorted lists), which the kernel uses to find a
+// floor for the k-th best from the list heads before touching the rest.
 #include "mtr_device.h"
 #include "wave_topk.h"
 
@@ -28,56 +30,129 @@ struct MergeArgs {
     long long idx_offset;
     long long* out_i;
     float* out_s;
+    int heads_first;  // lists are sorted: use the list heads to bound the k-th best first
 };
+
+struct Cand {
+    float s;
+    long long id;
+    bool ok;
+};
+
+__device__ __forceinline__ Cand load_cand(const MergeArgs& a, long long qbase, long long l, long long j, bool in_range) {
+    Cand c{0.f, -1, false};
+    if (in_range) {
+        const long long off = l * a.list_stride + qbase + j;
+        c.s = a.cs[off];
+        c.id = a.ci32 ? (long long)a.ci32[off] : a.ci64[off];
+        c.ok = c.id >= 0;
+        if (a.ci32) c.id += a.idx_offset;
+    }
+    return c;
+}
+
+// Folds the lists of waves 1.. into wave 0's (called by wave 0 after a barrier).
+__device__ __forceinline__ void fold_wave_lists(WaveTopK<long long>& tk, const float* list_s, const long long* list_i,
+                                                const int* cnt_lds, int nwaves, int k, int lane) {
+    for (int w = 1; w < nwaves; ++w) {
+        const int c = cnt_lds[w];
+        const float* ws = list_s + (size_t)w * k;
+        const long long* wi = list_i + (size_t)w * k;
+        for (int j0 = 0; j0 < c; j0 += 64) {
+            const int j = j0 + lane;
+            const bool ok = j < c;
+            tk.push(ok ? ws[j] : 0.f, ok ? wi[j] : 0ll, ok);
+        }
+    }
+}
+
+constexpr int kQueueCap = 512;  // survivors staged in LDS for wave 0
 
 __global__ void merge_topk_kernel(MergeArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nwaves = blockDim.x >> 6;
     long long* list_i = reinterpret_cast<long long*>(smem);
-    float* list_s = reinterpret_cast<float*>(list_i + (size_t)nwaves * a.k_out);
-    int* cnt_lds = reinterpret_cast<int*>(list_s + (size_t)nwaves * a.k_out);
+    long long* queue_i = list_i + (size_t)nwaves * a.k_out;
+    float* list_s = reinterpret_cast<float*>(queue_i + kQueueCap);
+    float* queue_s = list_s + (size_t)nwaves * a.k_out;
+    int* cnt_lds = reinterpret_cast<int*>(queue_s + kQueueCap);
+    float* floor_lds = reinterpret_cast<float*>(cnt_lds + nwaves);
+    int* qcount = reinterpret_cast<int*>(floor_lds + 1);
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int q = blockIdx.x;
+    const long long qbase = (long long)q * a.query_stride;
+    constexpr int kUnroll = 8;
 
     WaveTopK<long long> tk;
     tk.init(list_s + (size_t)wave * a.k_out, list_i + (size_t)wave * a.k_out, a.k_out);
+    if (threadIdx.x == 0) {
+        qcount[0] = 0;
+        floor_lds[0] = -__builtin_huge_valf();
+    }
+    __syncthreads();
 
-    const long long total = (long long)a.n_lists * a.k_in;
-    const long long qbase = (long long)q * a.query_stride;
-    for (long long m0 = (long long)wave * 64; m0 < total; m0 += (long long)nwaves * 64) {
-        const long long m = m0 + lane;
-        bool ok = m < total;
-        float s = 0.f;
-        long long id = -1;
-        if (ok) {
-            const long long l = m / a.k_in;
-            const long long j = m - l * a.k_in;
-            const long long off = l * a.list_stride + qbase + j;
-            s = a.cs[off];
-            id = a.ci32 ? (long long)a.ci32[off] : a.ci64[off];
-            ok = id >= 0;
-            if (a.ci32) id += a.idx_offset;
+    // Pass 1 (many lists only): the k-th best of the list HEADS is a floor for
+    // the k-th best overall; with sorted lists almost nothing else clears it,
+    // so pass 2 keeps a handful of candidates instead of thousands.  One wave
+    // does this: folding per-wave head lists would cost more than it saves.
+    if (a.heads_first) {
+        if (wave == 0) {
+            for (long long l0 = 0; l0 < a.n_lists; l0 += 64 * kUnroll) {
+                Cand c[kUnroll];
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) {
+                    const long long l = l0 + u * 64 + lane;
+                    c[u] = load_cand(a, qbase, l, 0, l < a.n_lists);
+                }
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) tk.push(c[u].s, c[u].id, c[u].ok);
+            }
+            if (lane == 0 && tk.cnt == a.k_out) floor_lds[0] = tk.thr_s;
+            tk.init(list_s, list_i, a.k_out);
         }
-        tk.push(s, id, ok);
+        __syncthreads();
+    }
+    const float floor_s = floor_lds[0];
+
+    // Pass 2: candidates that reach the floor go to the LDS queue (or, if it is
+    // full, through this wave's own list).  Loads are issued kUnroll at a time.
+    const long long total = (long long)a.n_lists * a.k_in;
+    const long long stride = (long long)nwaves * 64;
+    for (long long m0 = (long long)wave * 64; m0 < total; m0 += stride * kUnroll) {
+        Cand c[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const long long m = m0 + u * stride + lane;
+            const long long l = m / a.k_in;
+            c[u] = load_cand(a, qbase, l, m - l * a.k_in, m < total);
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            bool keep = c[u].ok && c[u].s >= floor_s;
+            if (keep) {
+                const int pos = atomicAdd(qcount, 1);
+                if (pos < kQueueCap) {
+                    queue_s[pos] = c[u].s;
+                    queue_i[pos] = c[u].id;
+                    keep = false;
+                }
+            }
+            tk.push(c[u].s, c[u].id, keep);  // queue overflow only
+        }
     }
 
     if (lane == 0) cnt_lds[wave] = tk.cnt;
     __syncthreads();
     if (wave == 0) {
-        for (int w = 1; w < nwaves; ++w) {
-            const int c = cnt_lds[w];
-            const float* ws = list_s + (size_t)w * a.k_out;
-            const long long* wi = list_i + (size_t)w * a.k_out;
-            for (int j0 = 0; j0 < c; j0 += 64) {
-                const int j = j0 + lane;
-                const bool ok = j < c;
-                const float s = ok ? ws[j] : 0.f;
-                const long long id = ok ? wi[j] : 0;
-                tk.push(s, id, ok);
-            }
+        const int nq = qcount[0] < kQueueCap ? qcount[0] : kQueueCap;
+        for (int j0 = 0; j0 < nq; j0 += 64) {
+            const int j = j0 + lane;
+            const bool ok = j < nq;
+            tk.push(ok ? queue_s[j] : 0.f, ok ? queue_i[j] : 0ll, ok);
         }
+        fold_wave_lists(tk, list_s, list_i, cnt_lds, nwaves, a.k_out, lane);
         float* os = a.out_s + (size_t)q * a.k_out;
         long long* oi = a.out_i + (size_t)q * a.k_out;
         for (int j = lane; j < a.k_out; j += 64) {
@@ -94,12 +169,13 @@ hipError_t launch_merge_topk(const float* cand_s, const int* idx32, const long l
                              long long list_stride, long long query_stride, int k_in, int b, int k_out,
                              long long idx_offset, long long* out_idx, float* out_score, hipStream_t stream) {
     if (b < 1 || k_out < 1 || k_in < 1 || n_lists < 1) return hipErrorInvalidValue;
-    MergeArgs a{cand_s, idx32, idx64, n_lists, list_stride, query_stride, k_in, k_out, idx_offset, out_idx, out_score};
+    MergeArgs a{cand_s, idx32, idx64, n_lists, list_stride, query_stride, k_in, k_out, idx_offset, out_idx, out_score,
+                (n_lists >= 4 * k_out && n_lists >= 128) ? 1 : 0};
     const long long total = (long long)n_lists * k_in;
     int nwaves = 16;
     while (nwaves > 1 && (long long)nwaves * 64 * 2 > total) nwaves /= 2;            // no idle waves on short inputs
-    while (nwaves > 1 && (size_t)nwaves * k_out * 12 + 64 > 60 * 1024) nwaves /= 2;  // LDS budget
-    const size_t lds = (size_t)nwaves * k_out * 12 + (size_t)nwaves * 4;
+    while (nwaves > 1 && (size_t)nwaves * k_out * 12 + kQueueCap * 12 + 128 > 60 * 1024) nwaves /= 2;  // LDS budget
+    const size_t lds = (size_t)nwaves * k_out * 12 + (size_t)kQueueCap * 12 + (size_t)nwaves * 4 + 16;
     hipLaunchKernelGGL(merge_topk_kernel, dim3(b), dim3(nwaves * 64), lds, stream, a);
     return hipGetLastError();
 }

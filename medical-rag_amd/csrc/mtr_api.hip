@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -95,6 +96,8 @@ struct mtr_index {
     DevBuf q_f32;      // padded fp32 queries of one pass
     DevBuf q_in;       // staging for host queries
     DevBuf cand_s, cand_i;
+    DevBuf q_bf16;     // bf16 query tiles for the matrix-core kernel
+    DevBuf mfma_cand;  // its workgroups' candidate buffers
     DevBuf out_i, out_s;
     DevBuf stage;      // staging for host rows
     void* pinned = nullptr;
@@ -117,10 +120,61 @@ int check_index(const mtr_index* ix) {
 // Scoring + merge of one batch, enqueued on `stream`.  dev_queries: b x d in
 // q_dtype on the shard's device.  check_flag: leave the loader's non-finite
 // flag set for the caller to read.
+// Smallest batch that goes to the matrix-core kernel (bf16 shards only); below
+// it the HBM-bound scan handles the batch in passes of up to 8 queries.
+int mfma_min_batch() {
+    static const int v = [] {
+        const char* e = getenv("MTR_MFMA_MIN_BATCH");
+        const int x = e ? atoi(e) : 0;
+        return x > 0 ? x : 17;
+    }();
+    return v;
+}
+
+// Matrix-core path: bf16 queries, one fused score + top-k launch, then the
+// merge of the per-range lists.
+int enqueue_mfma(mtr_index* ix, const mtr::MfmaPlan& plan, const void* dev_queries, int q_dtype, int b, int k,
+                 int metric, long long* dev_out_idx, float* dev_out_score, hipStream_t stream) {
+    int rc;
+    const size_t qbytes = (size_t)plan.n_qtiles * 128 * ix->ld * 2;
+    if ((rc = ix->q_bf16.reserve(qbytes)) != MTR_OK) return rc;
+    if ((rc = ix->mfma_cand.reserve(plan.cand_bytes)) != MTR_OK) return rc;
+    if ((rc = ix->cand_s.reserve((size_t)b * plan.n_ranges * k * 4)) != MTR_OK) return rc;
+    if ((rc = ix->cand_i.reserve((size_t)b * plan.n_ranges * k * 4)) != MTR_OK) return rc;
+    HIP_TRY(hipMemsetAsync(ix->q_bf16.p, 0, qbytes, stream));
+    HIP_TRY(mtr::launch_load_rows(dev_queries, q_dtype, b, ix->d, ix->q_bf16.p, MTR_BF16, ix->ld,
+                                  metric == MTR_COSINE ? 1 : 0, ix->flag, stream));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ix->profiling) {
+        if (ix->events_used == ix->events.size()) {
+            hipEvent_t a, c;
+            HIP_TRY(hipEventCreate(&a));
+            HIP_TRY(hipEventCreate(&c));
+            ix->events.emplace_back(a, c);
+        }
+        e0 = ix->events[ix->events_used].first;
+        e1 = ix->events[ix->events_used].second;
+        ix->events_used++;
+        HIP_TRY(hipEventRecord(e0, stream));
+    }
+    HIP_TRY(mtr::launch_score_mfma(ix->rows, ix->n, ix->ld, ix->q_bf16.p, b, k, plan, ix->mfma_cand.p,
+                                   static_cast<float*>(ix->cand_s.p), static_cast<int*>(ix->cand_i.p), stream));
+    if (ix->profiling) HIP_TRY(hipEventRecord(e1, stream));
+    HIP_TRY(mtr::launch_merge_topk(static_cast<const float*>(ix->cand_s.p), static_cast<const int*>(ix->cand_i.p),
+                                   nullptr, plan.n_ranges, (long long)k, (long long)plan.n_ranges * k, k, b, k,
+                                   ix->row_offset, dev_out_idx, dev_out_score, stream));
+    return MTR_OK;
+}
+
 int enqueue_search(mtr_index* ix, const void* dev_queries, int q_dtype, int b, int k, int metric,
                    long long* dev_out_idx, float* dev_out_score, hipStream_t stream) {
     if (metric == MTR_COSINE && !ix->normalized)
         return fail(MTR_ERR_INVALID, "cosine search needs a shard built with normalize=1");
+    if (ix->dtype == MTR_BF16 && b >= mfma_min_batch()) {
+        mtr::MfmaPlan mplan;
+        if (mtr::plan_mfma(ix->n, ix->ld, b, k, ix->num_cus, &mplan) == 0)
+            return enqueue_mfma(ix, mplan, dev_queries, q_dtype, b, k, metric, dev_out_idx, dev_out_score, stream);
+    }
     mtr::ScanPlan plan;
     if (mtr::plan_scan(ix->dtype, ix->n, ix->d, ix->ld, b, k, ix->num_cus, &plan) != 0)
         return fail(MTR_ERR_INVALID, "unsupported search shape (d=%d, k=%d)", ix->d, k);
@@ -131,8 +185,9 @@ int enqueue_search(mtr_index* ix, const void* dev_queries, int q_dtype, int b, i
     const int qsize = dtype_size(q_dtype);
     for (int b0 = 0; b0 < b; b0 += plan.qb) {
         const int nb = std::min(plan.qb, b - b0);
-        // Padded fp32 queries; unused query slots of the pass are zero.
-        HIP_TRY(hipMemsetAsync(ix->q_f32.p, 0, (size_t)plan.qb * plan.qstride * 4, stream));
+        // Padded fp32 queries (the loader writes all qstride columns of each
+        // query it converts); unused query slots of a short pass are zeroed.
+        if (nb < plan.qb) HIP_TRY(hipMemsetAsync(ix->q_f32.p, 0, (size_t)plan.qb * plan.qstride * 4, stream));
         HIP_TRY(mtr::launch_load_rows(static_cast<const char*>(dev_queries) + (size_t)b0 * ix->d * qsize, q_dtype, nb,
                                       ix->d, ix->q_f32.p, MTR_F32, plan.qstride, metric == MTR_COSINE ? 1 : 0,
                                       ix->flag, stream));
@@ -402,6 +457,8 @@ void mtr_index_destroy(mtr_index_t* ix) {
         ix->q_in.release();
         ix->cand_s.release();
         ix->cand_i.release();
+        ix->q_bf16.release();
+        ix->mfma_cand.release();
         ix->out_i.release();
         ix->out_s.release();
         ix->stage.release();

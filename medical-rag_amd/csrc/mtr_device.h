@@ -80,4 +80,24 @@ hipError_t launch_merge_topk(const float* cand_s, const int* idx32, const long l
                              int b, int k_out, long long idx_offset, long long* out_idx,
                              float* out_score, hipStream_t stream);
 
+struct MfmaPlan {
+    int cap;                  // candidate slots per (workgroup, query): 256 or 512
+    int n_qtiles;             // query tiles of 128
+    int n_ranges;             // row ranges (= candidate lists per query)
+    long long tiles_per_range;
+    int grid;
+    size_t lds;
+    size_t cand_bytes;        // scratch for the workgroups' candidate buffers
+};
+
+// Launch shape of the matrix-core scoring kernel; -1 when the shape is not
+// covered (row stride not a multiple of 64 elements, or k > 256).
+int plan_mfma(int64_t n, int ld, int b, int k, int num_cus, MfmaPlan* plan);
+
+// bf16 rows x bf16 queries on the matrix cores with fused top-k.  queries_bf16:
+// [n_qtiles*128][ld], rows past b zero.  Outputs [b][n_ranges][k] candidate
+// lists (unsorted, padded with (-inf, -1)).
+hipError_t launch_score_mfma(const void* rows, int64_t n, int ld, const void* queries_bf16, int b, int k,
+                             const MfmaPlan& plan, void* cand_buf, float* out_s, int* out_i, hipStream_t stream);
+
 }  // namespace mtr

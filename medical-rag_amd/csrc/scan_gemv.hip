@@ -30,7 +30,10 @@ namespace mtr {
 
 namespace {
 
-constexpr int kWaves = 4;  // waves per workgroup
+// Waves per workgroup: one 16-wave workgroup per CU when a single query leaves
+// room for 4 waves per SIMD (128 registers), 8-wave workgroups otherwise.  Large
+// workgroups keep the number of candidate lists (one per workgroup) small.
+constexpr int waves_per_group(int qb) { return qb == 1 ? 16 : 8; }
 // Rows per wave group: 8 for one or two queries, 4 beyond (register budget).
 constexpr int rows_per_group(int qb) { return qb <= 2 ? 8 : 4; }
 
@@ -80,7 +83,8 @@ struct ScanArgs {
 };
 
 template <typename T, int QB, bool NT>
-__global__ __launch_bounds__(kWaves * 64) void scan_topk_kernel(ScanArgs a) {
+__global__ __launch_bounds__(waves_per_group(QB) * 64) void scan_topk_kernel(ScanArgs a) {
+    constexpr int kWaves = waves_per_group(QB);
     constexpr int EPC = Chunk<T>::EPC;
     constexpr int R = rows_per_group(QB);
     constexpr int V = R * QB;
@@ -168,16 +172,19 @@ __global__ __launch_bounds__(kWaves * 64) void scan_topk_kernel(ScanArgs a) {
         for (int b = 0; b < QB; ++b) tk[b].push(total, (int)row, valid && my_b == b);
     }
 
-    // Merge the four waves' lists into wave 0's and write the workgroup's lists.
-    if (lane == 0) {
+    // Fold the waves' lists pairwise (wave w takes wave w + half, halving the
+    // number of live lists per round), then wave 0 writes the workgroup's lists.
 #pragma unroll
-        for (int b = 0; b < QB; ++b) cnt_lds[wave * QB + b] = tk[b].cnt;
-    }
-    __syncthreads();
-    if (wave == 0) {
+    for (int half = kWaves / 2; half >= 1; half >>= 1) {
+        if (lane == 0 && wave < 2 * half) {
 #pragma unroll
-        for (int b = 0; b < QB; ++b) {
-            for (int w = 1; w < kWaves; ++w) {
+            for (int b = 0; b < QB; ++b) cnt_lds[wave * QB + b] = tk[b].cnt;
+        }
+        __syncthreads();
+        if (wave < half) {
+            const int w = wave + half;
+#pragma unroll
+            for (int b = 0; b < QB; ++b) {
                 const int c = cnt_lds[w * QB + b];
                 const float* ws = list_s + (w * QB + b) * a.k;
                 const int* wi = list_i + (w * QB + b) * a.k;
@@ -189,6 +196,12 @@ __global__ __launch_bounds__(kWaves * 64) void scan_topk_kernel(ScanArgs a) {
                     tk[b].push(s, i, ok);
                 }
             }
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
+#pragma unroll
+        for (int b = 0; b < QB; ++b) {
             float* os = a.cand_s + ((size_t)b * gridDim.x + blockIdx.x) * a.k;
             int* oi = a.cand_i + ((size_t)b * gridDim.x + blockIdx.x) * a.k;
             for (int j = lane; j < a.k; j += 64) {
@@ -201,19 +214,25 @@ __global__ __launch_bounds__(kWaves * 64) void scan_topk_kernel(ScanArgs a) {
 }
 
 size_t scan_lds_bytes(int qb, int qstride, int k) {
+    const int kWaves = waves_per_group(qb);
     return (size_t)qb * qstride * 4 + (size_t)kWaves * qb * k * 8 + (size_t)kWaves * qb * 4;
 }
 
 template <typename T, int QB, bool NT>
 hipError_t launch_one(const ScanArgs& a, const ScanPlan& plan, hipStream_t stream) {
-    hipLaunchKernelGGL((scan_topk_kernel<T, QB, NT>), dim3(plan.grid), dim3(kWaves * 64), plan.lds, stream, a);
+    if (plan.lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_topk_kernel<T, QB, NT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((scan_topk_kernel<T, QB, NT>), dim3(plan.grid), dim3(waves_per_group(QB) * 64), plan.lds, stream, a);
     return hipGetLastError();
 }
 
 template <typename T, int QB, bool NT>
 int occupancy_of(size_t lds) {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, scan_topk_kernel<T, QB, NT>, kWaves * 64, lds) != hipSuccess)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, scan_topk_kernel<T, QB, NT>, waves_per_group(QB) * 64, lds) != hipSuccess)
         nb = 1;
     return nb < 1 ? 1 : nb;
 }
@@ -250,7 +269,7 @@ int plan_scan(int dtype, int64_t n, int d, int ld, int b, int k, int num_cus, Sc
     plan->qstride = plan->nit * 64 * epc;
     int qb = 1;
     while (qb < b && qb < 8) qb *= 2;
-    constexpr size_t kLdsBudget = 64 * 1024;
+    constexpr size_t kLdsBudget = 150 * 1024;  // of the CU's 160 KiB
     while (qb > 1 && scan_lds_bytes(qb, plan->qstride, k) > kLdsBudget) qb /= 2;
     if (scan_lds_bytes(qb, plan->qstride, k) > kLdsBudget) return -1;
     plan->qb = qb;
@@ -264,6 +283,7 @@ int plan_scan(int dtype, int64_t n, int d, int ld, int b, int k, int num_cus, Sc
         occ = plan->nontemporal ? occupancy_qb<bf16_t, true>(qb, plan->lds) : occupancy_qb<bf16_t, false>(qb, plan->lds);
     const int rpg = rows_per_group(qb);
     const long long ngroups = (n + rpg - 1) / rpg;
+    const int kWaves = waves_per_group(qb);
     long long want = (ngroups + kWaves - 1) / kWaves;
     const long long cap = (long long)num_cus * occ;
     plan->grid = (int)(want < cap ? want : cap);

@@ -1,0 +1,327 @@
+// Batched scoring on the matrix cores with the top-k selection fused in: a
+// tiled  rows x queries  bf16 contraction (v_mfma_f32_32x32x16_bf16) whose
+// score tiles never leave the registers.
+//
+// This is the many-queries form of retrieve_top_index
+// (pipeline/utils/local_rag.py:76-78): all unique keyword vectors of a run
+// (pipeline/async_main.py:193-195) scored in one pass over the page matrix.
+//
+// Work split.  Queries are cut into tiles of 128, the stored rows into ranges;
+// one workgroup (4 waves) owns one (query tile, row range) pair and sweeps the
+// range in tiles of 128 rows.  Workgroups that share a query tile are placed on
+// one XCD (consecutive ids after the XCD remap), so that tile stays in that
+// XCD's L2 while every XCD streams the rows.
+//
+// Per 128x128 tile.  K runs over the row width in steps of 64: both operands
+// are K-contiguous (scores = rows . queries^T), so the row tile and the query
+// tile are staged with 16-byte direct-to-LDS loads into two buffers (the next
+// step's loads are issued before this step's MFMAs; one barrier per step).
+// The LDS image is 128-byte rows whose 16-byte chunks are XOR-swizzled with
+// the row number -- applied on the global source address, since a
+// direct-to-LDS load writes lane-linear -- which makes the ds_read_b128
+// fragment reads conflict-free.  Each wave computes a 64x64 sub-tile as 2x2
+// MFMA tiles with the rows as the A operand: the accumulator then holds ONE
+// query per lane (column = lane & 31) and 16 rows per register set, so the
+// per-query threshold test is one compare per lane.
+//
+// Fused top-k.  Each query keeps in LDS the score of its current k-th best
+// (the floor) and a count; scores above the floor are appended, as packed
+// 64-bit keys (wave_select.h), to the workgroup's private candidate buffer in
+// global memory (L2-resident).  When a query's buffer could overflow on the
+// next tile, one wave re-selects its k best with a radix walk, which also
+// raises the floor.  Rows arrive in increasing order, so "strictly above the
+// floor" never drops a row that would win a tie.  At the end every query's k
+// best are written as one candidate list per row range; merge_topk.hip merges
+// the ranges.
+//
+// Algorithmic work per launch: 2 * B * n * d flops (bf16 MFMA, fp32 accumulate).
+#include "mtr_device.h"
+#include "wave_select.h"
+
+namespace mtr {
+
+namespace {
+
+constexpr int TM = 128;   // rows per tile
+constexpr int TN = 128;   // queries per tile
+constexpr int BK = 64;    // K elements per step
+constexpr int kThreads = 256;
+constexpr int kStageBytes = (TM + TN) * BK * 2;  // 32 KiB: row tile then query tile
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+struct MfmaArgs {
+    const bf16_t* rows;      // [n][ld]
+    long long n;
+    int ld;                  // elements, multiple of BK
+    const bf16_t* queries;   // [n_qtiles*TN][ld], zero rows past b
+    int b;
+    int n_qtiles;
+    int n_ranges;
+    long long tiles_per_range;
+    int k;
+    unsigned long long* cand_buf;  // [grid][TN][CAP]
+    float* out_s;            // [b][n_ranges][k]
+    int* out_i;
+};
+
+__device__ __forceinline__ void stage_tile(const bf16_t* base, long long row0, long long row_max, int ld, int k0,
+                                           char* lds, int wave, int lane) {
+    // 128 rows x 128 bytes.  One wave instruction fills 8 rows; lane L writes
+    // LDS position (row L/8, slot L%8) and fetches chunk (L%8) ^ (L/8) of it.
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int t = wave * 4 + i;
+        const int r = t * 8 + (lane >> 3);
+        long long row = row0 + r;
+        row = row < row_max ? row : row_max;
+        const int chunk = (lane & 7) ^ (lane >> 3);
+        const bf16_t* src = base + row * ld + k0 + chunk * 8;
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(lds + t * 1024), 16, 0, 0);
+    }
+}
+
+__device__ __forceinline__ bf16x8 read_frag(const char* lds, int row, int chunk) {
+    return *reinterpret_cast<const bf16x8*>(lds + row * 128 + ((chunk ^ (row & 7)) << 4));
+}
+
+// Re-selects the k best keys of one query's buffer (c entries, c <= 64*E),
+// compacts them to the front, and publishes the new count and floor.
+template <int E>
+__device__ __forceinline__ void compact_query(unsigned long long* buf, int c, int k, float* floor_lds, int* cnt_lds,
+                                              int q, int lane) {
+    unsigned long long key[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = e * 64 + lane;
+        key[e] = i < c ? buf[i] : 0ull;
+    }
+    const unsigned long long cut = wave_kth_largest<E>(key, k);
+    int base = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const bool keep = key[e] != 0ull && key[e] >= cut;
+        const unsigned long long m = __ballot(keep);
+        const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+        if (keep) buf[pos] = key[e];
+        base += __popcll(m);
+    }
+    if (lane == 0) {
+        cnt_lds[q] = base;
+        if (cut != 0ull) floor_lds[q] = key_score(cut);
+    }
+}
+
+template <int CAP>
+__global__ __launch_bounds__(kThreads, 2) void score_topk_mfma_kernel(MfmaArgs a) {
+    constexpr int E = CAP / 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const stage0 = smem;
+    float* floor_lds = reinterpret_cast<float*>(smem + 2 * kStageBytes);
+    int* cnt_lds = reinterpret_cast<int*>(floor_lds + TN);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1;  // which 64 rows of the tile
+    const int wn = wave & 1;   // which 64 queries of the tile
+
+    // XCD-aware, bijective workgroup remap: ids that land on one XCD become consecutive.
+    const int nwg = gridDim.x;
+    const int xcd = blockIdx.x % 8;
+    const int per = nwg / 8, rem = nwg % 8;
+    const int wgid = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + blockIdx.x / 8;
+    const int qt = wgid / a.n_ranges;
+    const int range = wgid % a.n_ranges;
+
+    const long long n_tiles = (a.n + TM - 1) / TM;
+    const long long tile_lo = (long long)range * a.tiles_per_range;
+    long long tile_hi = tile_lo + a.tiles_per_range;
+    if (tile_hi > n_tiles) tile_hi = n_tiles;
+    const long long my_tiles = tile_hi > tile_lo ? tile_hi - tile_lo : 0;
+    const int ksteps = a.ld / BK;
+
+    for (int i = tid; i < TN; i += kThreads) {
+        const int qg = qt * TN + i;
+        floor_lds[i] = qg < a.b ? -__builtin_huge_valf() : __builtin_huge_valf();  // padding queries collect nothing
+        cnt_lds[i] = 0;
+    }
+    unsigned long long* my_buf = a.cand_buf + (size_t)blockIdx.x * TN * CAP;
+    const bf16_t* qbase = a.queries + (size_t)qt * TN * a.ld;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    const long long total_steps = my_tiles * ksteps;
+    if (total_steps > 0) {
+        stage_tile(a.rows, tile_lo * TM, a.n - 1, a.ld, 0, stage0, wave, lane);
+        stage_tile(qbase, 0, TN - 1, a.ld, 0, stage0 + TM * BK * 2, wave, lane);
+    }
+    __syncthreads();
+
+    long long tile = tile_lo;
+    int ks = 0;
+    for (long long s = 0; s < total_steps; ++s) {
+        const int cur = (int)(s & 1);
+        if (s + 1 < total_steps) {
+            const int nks = ks + 1 == ksteps ? 0 : ks + 1;
+            const long long ntile = ks + 1 == ksteps ? tile + 1 : tile;
+            stage_tile(a.rows, ntile * TM, a.n - 1, a.ld, nks * BK, stage0 + (cur ^ 1) * kStageBytes, wave, lane);
+            stage_tile(qbase, 0, TN - 1, a.ld, nks * BK, stage0 + (cur ^ 1) * kStageBytes + TM * BK * 2, wave, lane);
+        }
+        const char* sa = stage0 + cur * kStageBytes;
+        const char* sb = stage0 + cur * kStageBytes + TM * BK * 2;
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            const int chunk = 2 * kk + (lane >> 5);
+            bf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) fa[m] = read_frag(sa, wm * 64 + m * 32 + (lane & 31), chunk);
+#pragma unroll
+            for (int n = 0; n < 2; ++n) fb[n] = read_frag(sb, wn * 64 + n * 32 + (lane & 31), chunk);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m], fb[n], acc[m][n], 0, 0, 0);
+        }
+
+        const bool tile_done = ks + 1 == ksteps;
+        if (tile_done) {
+            // Scores of 128 rows x 128 queries are complete: append what clears each query's floor.
+            const long long row_base = tile * TM + wm * 64 + 4 * (lane >> 5);
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int ql = wn * 64 + n * 32 + (lane & 31);
+                const float fl = floor_lds[ql];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    float mx = acc[m][n][0];
+#pragma unroll
+                    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[m][n][r]);
+                    if (__any(mx > fl)) {
+                        if (mx > fl) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const float v = acc[m][n][r];
+                                const long long row = row_base + m * 32 + (r & 3) + 8 * (r >> 2);
+                                if (v > fl && row < a.n) {
+                                    const int slot = atomicAdd(&cnt_lds[ql], 1);
+                                    my_buf[(size_t)ql * CAP + slot] = pack_key(v, (int)row);
+                                }
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+                }
+            }
+        }
+        __syncthreads();
+        if (tile_done) {
+            // Wave w looks after queries [32w, 32w+32): re-select any whose buffer
+            // could overflow on the next tile (a tile adds at most TM entries).
+            const int c = cnt_lds[wave * 32 + (lane & 31)];
+            unsigned long long need = __ballot(lane < 32 && c + TM > CAP);
+            while (need) {
+                const int j = __ffsll((long long)need) - 1;
+                need &= need - 1;
+                const int q = wave * 32 + j;
+                const int cq = __builtin_amdgcn_readfirstlane(cnt_lds[q]);
+                compact_query<E>(my_buf + (size_t)q * CAP, cq, a.k, floor_lds, cnt_lds, q, lane);
+            }
+            ks = 0;
+            ++tile;
+            if (ksteps == 1) __syncthreads();  // no other barrier separates this from the next tile's appends
+        } else {
+            ++ks;
+        }
+    }
+
+    // Final selection per query and one candidate list per (query, range).
+    __syncthreads();
+    for (int j = 0; j < 32; ++j) {
+        const int q = wave * 32 + j;
+        const int qg = qt * TN + q;
+        if (qg >= a.b) continue;  // wave-uniform
+        int cq = __builtin_amdgcn_readfirstlane(cnt_lds[q]);
+        unsigned long long* buf = my_buf + (size_t)q * CAP;
+        if (cq > a.k) {
+            compact_query<E>(buf, cq, a.k, floor_lds, cnt_lds, q, lane);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            cq = __builtin_amdgcn_readfirstlane(cnt_lds[q]);
+        }
+        float* os = a.out_s + ((size_t)qg * a.n_ranges + range) * a.k;
+        int* oi = a.out_i + ((size_t)qg * a.n_ranges + range) * a.k;
+        for (int i = lane; i < a.k; i += 64) {
+            if (i < cq) {
+                const unsigned long long key = buf[i];
+                os[i] = key_score(key);
+                oi[i] = key_row(key);
+            } else {
+                os[i] = -__builtin_huge_valf();
+                oi[i] = -1;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+int plan_mfma(int64_t n, int ld, int b, int k, int num_cus, MfmaPlan* plan) {
+    if (ld % BK != 0 || k < 1 || k > 256 || b < 1 || n < 1) return -1;
+    plan->cap = k <= 32 ? 256 : 512;
+    plan->n_qtiles = (b + TN - 1) / TN;
+    const long long n_tiles = (n + TM - 1) / TM;
+    long long ranges = (2LL * num_cus + plan->n_qtiles - 1) / plan->n_qtiles;
+    if (ranges > n_tiles) ranges = n_tiles;
+    if (ranges < 1) ranges = 1;
+    plan->tiles_per_range = (n_tiles + ranges - 1) / ranges;
+    plan->n_ranges = (int)((n_tiles + plan->tiles_per_range - 1) / plan->tiles_per_range);
+    plan->grid = plan->n_qtiles * plan->n_ranges;
+    plan->lds = 2 * kStageBytes + TN * 8;
+    plan->cand_bytes = (size_t)plan->grid * TN * plan->cap * 8;
+    return 0;
+}
+
+hipError_t launch_score_mfma(const void* rows, int64_t n, int ld, const void* queries_bf16, int b, int k,
+                             const MfmaPlan& plan, void* cand_buf, float* out_s, int* out_i, hipStream_t stream) {
+    MfmaArgs a;
+    a.rows = static_cast<const bf16_t*>(rows);
+    a.n = n;
+    a.ld = ld;
+    a.queries = static_cast<const bf16_t*>(queries_bf16);
+    a.b = b;
+    a.n_qtiles = plan.n_qtiles;
+    a.n_ranges = plan.n_ranges;
+    a.tiles_per_range = plan.tiles_per_range;
+    a.k = k;
+    a.cand_buf = static_cast<unsigned long long*>(cand_buf);
+    a.out_s = out_s;
+    a.out_i = out_i;
+    hipError_t e;
+    if (plan.cap == 256) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&score_topk_mfma_kernel<256>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(score_topk_mfma_kernel<256>, dim3(plan.grid), dim3(kThreads), plan.lds, stream, a);
+    } else {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&score_topk_mfma_kernel<512>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(score_topk_mfma_kernel<512>, dim3(plan.grid), dim3(kThreads), plan.lds, stream, a);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace mtr

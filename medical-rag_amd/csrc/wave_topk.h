@@ -28,14 +28,15 @@ template <typename IdxT> struct IdxMax;
 template <> struct IdxMax<int> { static constexpr int value = INT_MAX; };
 template <> struct IdxMax<long long> { static constexpr long long value = LLONG_MAX; };
 
-template <typename IdxT>
-__device__ __forceinline__ IdxT bcast_lane(IdxT v, int lane);
-template <>
-__device__ __forceinline__ int bcast_lane<int>(int v, int lane) { return __shfl(v, lane, 64); }
-template <>
-__device__ __forceinline__ long long bcast_lane<long long>(long long v, int lane) {
-    int lo = __shfl((int)(v & 0xffffffffll), lane, 64);
-    int hi = __shfl((int)(v >> 32), lane, 64);
+// Broadcast of one lane's value; `lane` must be wave-uniform (it always comes
+// from a ballot mask here), which makes this a v_readlane, not an LDS permute.
+__device__ __forceinline__ float bcast_lane(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ int bcast_lane(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ long long bcast_lane(long long v, int lane) {
+    const int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffffll), lane);
+    const int hi = __builtin_amdgcn_readlane((int)(v >> 32), lane);
     return ((long long)hi << 32) | (unsigned int)lo;
 }
 
@@ -81,8 +82,8 @@ struct WaveTopK {
             while (m) {  // wave-uniform loop over the passing lanes
                 const int j = __ffsll((long long)m) - 1;
                 m &= m - 1;
-                const float js = __shfl(s, j, 64);
-                const IdxT ji = bcast_lane<IdxT>(i, j);
+                const float js = bcast_lane(s, j);
+                const IdxT ji = bcast_lane(i, j);
                 const bool jb = have && beats<IdxT>(js, ji, es, ei);  // pair j beats this entry
                 shift += jb ? 1 : 0;
                 const unsigned long long ahead = __ballot(have && !jb);  // entries that beat pair j
@@ -101,8 +102,8 @@ struct WaveTopK {
             while (m) {
                 const int j = __ffsll((long long)m) - 1;
                 m &= m - 1;
-                const float js = __shfl(s, j, 64);
-                const IdxT ji = bcast_lane<IdxT>(i, j);
+                const float js = bcast_lane(s, j);
+                const IdxT ji = bcast_lane(i, j);
                 if (pass && beats<IdxT>(js, ji, s, i)) my_rank += 1;
             }
         }

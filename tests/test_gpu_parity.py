@@ -294,3 +294,55 @@ def test_full_size_properties(native):
     resc = np.einsum("ij,ij->i", stored, np.repeat(qn, k, axis=0)).reshape(b, k)
     np.testing.assert_allclose(s1.cpu().numpy(), resc, atol=1e-5)
     whole.close()
+
+
+MFMA_SHAPES = [
+    # n, d, b, k   (bf16 rows whose stride is a multiple of 64 and b >= 17 take the matrix-core kernel)
+    (4097, 768, 40, 10),
+    (2500, 1024, 130, 100),
+    (1000, 64, 17, 256),
+    (129, 128, 200, 5),
+    (70000, 256, 64, 32),
+    (300, 192, 257, 300),   # k > 256: served by the scan instead
+]
+
+
+@pytest.mark.parametrize("n,d,b,k", MFMA_SHAPES)
+def test_matrix_core_path(rag, n, d, b, k):
+    rng = np.random.default_rng(n + d + b + k)
+    corpus = rng.standard_normal((n, d)).astype(np.float32)
+    queries = rng.standard_normal((b, d)).astype(np.float32)
+    corpus[n // 2] = corpus[1]
+    corpus[n - 1] = corpus[1] * 2.0
+    queries[0] = corpus[1] * 3.0  # hits the tie set exactly
+    index = rag.PageIndex.from_matrix(corpus, store_dtype="bf16")
+    idx, score = index.search(queries, k=k)
+    s64 = orc.scores(queries, corpus)
+    # rows AND queries are rounded to bf16 here: 1e-3 holds from d of a few hundred; below, the bf16 bound
+    tol = 1e-3 if d >= 256 else 2.0 ** -8
+    nt = check_topk(idx, score, s64, k, tol)
+    # bit-equal stored rows tie exactly: lowest row first
+    row = idx[0].tolist()
+    assert row[:3] == [1, n // 2, n - 1], row[:5]
+    print(f"mfma {n}x{d} b={b} k={k}: {nt} near-tie differences")
+    index.close()
+
+
+def test_matrix_core_matches_scan(native):
+    """Both kernels on the same bf16 shard: identical row sets apart from
+    near-ties (the scan keeps fp32 queries, the matrix-core path rounds them)."""
+    import os
+    import torch
+    rng = np.random.default_rng(77)
+    n, d, b, k = 30000, 512, 48, 20
+    corpus = rng.standard_normal((n, d)).astype(np.float32)
+    queries = rng.standard_normal((b, d)).astype(np.float32)
+    shard = native.DeviceShard.from_host(corpus, store_dtype="bf16")
+    big_i, big_s = shard.search(queries, k=k)                       # b >= 17: matrix cores
+    parts = [shard.search(queries[i:i + 8], k=k) for i in range(0, b, 8)]  # b = 8: scan
+    scan_i = np.concatenate([p[0] for p in parts]); scan_s = np.concatenate([p[1] for p in parts])
+    stored = shard.read_rows().astype(np.float64)
+    s64 = orc.normalize_rows(queries) @ stored.T   # exact scores of the STORED rows
+    check_topk(scan_i, scan_s, s64, k, 1e-5)
+    check_topk(big_i, big_s, s64, k, 1e-3)
+    shard.close()
