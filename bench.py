@@ -109,6 +109,8 @@ def main():
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--k", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="initialise the process group and run the all-gather + merge even with one rank")
     args = ap.parse_args()
 
     import torch
@@ -122,8 +124,10 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    if world > 1 or args.force_exchange:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
 
     w = dict(WORKLOADS[args.workload])
     if args.rows:
@@ -147,7 +151,7 @@ def main():
     shard = build_shard(native, torch, lo, hi, dim, store, local_rank, needles, queries, k)
     torch.cuda.synchronize()
     t_build = time.perf_counter() - t_build
-    index = ShardedIndex(shard)
+    index = ShardedIndex(shard, always_exchange=args.force_exchange)
 
     def step():
         return index.search_device(queries, k=k, metric="cosine")
@@ -233,7 +237,7 @@ def main():
             res["cpu_baseline"] = cpu_baseline(dim, k, rows)
         print(json.dumps(res), flush=True)
     shard.close()
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
     if not needle_ok:
         raise SystemExit("planted needle rows were not returned")

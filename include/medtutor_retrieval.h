@@ -94,11 +94,14 @@ int mtr_index_search_device(mtr_index_t* index, const void* dev_queries, int32_t
 /* k-way merge of per-shard candidate lists on GPU device_id: inputs are
  * n_lists blocks of b x k_in (id, score) pairs laid out [list][b][k_in] --
  * exactly what an all-gather of each rank's mtr_index_search_device output
- * produces; ids < 0 are padding.  Writes the best k_out per query ordered by
+ * produces; ids < 0 are padding.  idx_list_stride / score_list_stride give the
+ * distance between consecutive lists in elements of the respective array
+ * (0 = dense, b*k_in), so ids and scores may sit in one gathered buffer.  Writes the best k_out per query ordered by
  * (score desc, id asc).  This is the exchange step of the row-sharded search;
  * the reference is single-shard (pipeline/utils/local_rag.py:78 is its whole
  * "merge"). */
 int mtr_merge_topk_device(const int64_t* dev_idx, const float* dev_score, int32_t n_lists,
+                          int64_t idx_list_stride, int64_t score_list_stride,
                           int32_t b, int32_t k_in, int32_t k_out,
                           int64_t* dev_out_idx, float* dev_out_score,
                           int32_t device_id, void* stream);

@@ -32,7 +32,7 @@ SIGNATURES = {
     "mtr_index_create": (_i32, [_vp, _i64, _i32, _i32, _i32, _i32, _i32, _i64, _pp]),
     "mtr_index_search": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "mtr_index_search_device": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
-    "mtr_merge_topk_device": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
+    "mtr_merge_topk_device": (_i32, [_vp, _vp, _i32, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
     "mtr_index_info": (_i32, [_vp, C.POINTER(_i64), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32),
                               C.POINTER(_i32), C.POINTER(_i64)]),
     "mtr_index_read_rows": (_i32, [_vp, _i64, _i64, _vp]),
@@ -243,20 +243,32 @@ class DeviceShard:
             pass
 
 
-def merge_topk_device(idx, score, k_out, stream=None):
-    """idx/score: (n_lists, B, k_in) int64 / float32 tensors on one GPU.
-    Returns (idx (B, k_out), score (B, k_out)) ordered by (score desc, id asc)."""
+def merge_topk_device(idx, score, k_out, stream=None, out=None):
+    """idx/score: (n_lists, B, k_in) int64 / float32 tensors on one GPU; their
+    list dimension may be strided (views into one gathered buffer), the inner
+    (B, k_in) block must be dense.  Returns (idx (B, k_out), score (B, k_out))
+    ordered by (score desc, id asc)."""
     import torch
     if idx.dim() != 3 or idx.shape != score.shape or not idx.is_cuda:
         raise ValueError("merge_topk_device wants (n_lists, B, k_in) GPU tensors")
-    idx = idx.contiguous()
-    score = score.contiguous()
     n_lists, b, k_in = idx.shape
-    out_i = torch.empty((b, k_out), dtype=torch.int64, device=idx.device)
-    out_s = torch.empty((b, k_out), dtype=torch.float32, device=idx.device)
+
+    def dense_inner(t):
+        return t.stride(2) == 1 and t.stride(1) == k_in and (n_lists == 1 or t.stride(0) >= b * k_in)
+
+    if not dense_inner(idx):
+        idx = idx.contiguous()
+    if not dense_inner(score):
+        score = score.contiguous()
+    if out is None:
+        out_i = torch.empty((b, k_out), dtype=torch.int64, device=idx.device)
+        out_s = torch.empty((b, k_out), dtype=torch.float32, device=idx.device)
+    else:
+        out_i, out_s = out
     if stream is None:
         stream = torch.cuda.current_stream(idx.device).cuda_stream
-    check(lib().mtr_merge_topk_device(C.c_void_p(idx.data_ptr()), C.c_void_p(score.data_ptr()), n_lists, b, k_in,
-                                      int(k_out), C.c_void_p(out_i.data_ptr()), C.c_void_p(out_s.data_ptr()),
+    check(lib().mtr_merge_topk_device(C.c_void_p(idx.data_ptr()), C.c_void_p(score.data_ptr()), n_lists,
+                                      idx.stride(0) if n_lists > 1 else 0, score.stride(0) if n_lists > 1 else 0,
+                                      b, k_in, int(k_out), C.c_void_p(out_i.data_ptr()), C.c_void_p(out_s.data_ptr()),
                                       idx.device.index or 0, C.c_void_p(stream)))
     return out_i, out_s

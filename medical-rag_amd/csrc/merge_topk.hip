@@ -23,7 +23,8 @@ struct MergeArgs {
     const int* ci32;
     const long long* ci64;
     int n_lists;
-    long long list_stride;
+    long long list_stride;    // elements between lists in the id array
+    long long list_stride_s;  // ... and in the score array
     long long query_stride;
     int k_in;
     int k_out;
@@ -43,7 +44,7 @@ __device__ __forceinline__ Cand load_cand(const MergeArgs& a, long long qbase, l
     Cand c{0.f, -1, false};
     if (in_range) {
         const long long off = l * a.list_stride + qbase + j;
-        c.s = a.cs[off];
+        c.s = a.cs[l * a.list_stride_s + qbase + j];
         c.id = a.ci32 ? (long long)a.ci32[off] : a.ci64[off];
         c.ok = c.id >= 0;
         if (a.ci32) c.id += a.idx_offset;
@@ -166,10 +167,10 @@ __global__ void merge_topk_kernel(MergeArgs a) {
 }  // namespace
 
 hipError_t launch_merge_topk(const float* cand_s, const int* idx32, const long long* idx64, int n_lists,
-                             long long list_stride, long long query_stride, int k_in, int b, int k_out,
+                             long long list_stride, long long list_stride_s, long long query_stride, int k_in, int b, int k_out,
                              long long idx_offset, long long* out_idx, float* out_score, hipStream_t stream) {
     if (b < 1 || k_out < 1 || k_in < 1 || n_lists < 1) return hipErrorInvalidValue;
-    MergeArgs a{cand_s, idx32, idx64, n_lists, list_stride, query_stride, k_in, k_out, idx_offset, out_idx, out_score,
+    MergeArgs a{cand_s, idx32, idx64, n_lists, list_stride, list_stride_s, query_stride, k_in, k_out, idx_offset, out_idx, out_score,
                 (n_lists >= 4 * k_out && n_lists >= 128) ? 1 : 0};
     const long long total = (long long)n_lists * k_in;
     int nwaves = 16;

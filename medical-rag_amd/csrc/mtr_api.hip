@@ -161,7 +161,7 @@ int enqueue_mfma(mtr_index* ix, const mtr::MfmaPlan& plan, const void* dev_queri
                                    static_cast<float*>(ix->cand_s.p), static_cast<int*>(ix->cand_i.p), stream));
     if (ix->profiling) HIP_TRY(hipEventRecord(e1, stream));
     HIP_TRY(mtr::launch_merge_topk(static_cast<const float*>(ix->cand_s.p), static_cast<const int*>(ix->cand_i.p),
-                                   nullptr, plan.n_ranges, (long long)k, (long long)plan.n_ranges * k, k, b, k,
+                                   nullptr, plan.n_ranges, (long long)k, (long long)k, (long long)plan.n_ranges * k, k, b, k,
                                    ix->row_offset, dev_out_idx, dev_out_score, stream));
     return MTR_OK;
 }
@@ -209,7 +209,7 @@ int enqueue_search(mtr_index* ix, const void* dev_queries, int q_dtype, int b, i
                                       stream));
         if (ix->profiling) HIP_TRY(hipEventRecord(e1, stream));
         HIP_TRY(mtr::launch_merge_topk(static_cast<const float*>(ix->cand_s.p), static_cast<const int*>(ix->cand_i.p),
-                                       nullptr, plan.grid, (long long)k, (long long)plan.grid * k, k, nb, k,
+                                       nullptr, plan.grid, (long long)k, (long long)k, (long long)plan.grid * k, k, nb, k,
                                        ix->row_offset, dev_out_idx + (size_t)b0 * k, dev_out_score + (size_t)b0 * k,
                                        stream));
     }
@@ -373,16 +373,20 @@ int mtr_index_search_device(mtr_index_t* ix, const void* dev_queries, int32_t q_
                           dev_out_score, s);
 }
 
-int mtr_merge_topk_device(const int64_t* dev_idx, const float* dev_score, int32_t n_lists, int32_t b, int32_t k_in,
-                          int32_t k_out, int64_t* dev_out_idx, float* dev_out_score, int32_t device_id,
-                          void* stream) {
+int mtr_merge_topk_device(const int64_t* dev_idx, const float* dev_score, int32_t n_lists, int64_t idx_list_stride,
+                          int64_t score_list_stride, int32_t b, int32_t k_in, int32_t k_out, int64_t* dev_out_idx,
+                          float* dev_out_score, int32_t device_id, void* stream) {
     if (!dev_idx || !dev_score || !dev_out_idx || !dev_out_score) return fail(MTR_ERR_INVALID, "NULL argument");
     if (n_lists < 1 || b < 1 || k_in < 1 || k_out < 1 || k_out > MTR_MAX_K)
         return fail(MTR_ERR_INVALID, "bad merge shape (lists=%d, b=%d, k_in=%d, k_out=%d)", n_lists, b, k_in, k_out);
     DeviceGuard guard(device_id);
     if (!guard.ok) return fail(MTR_ERR_HIP, "hipSetDevice(%d) failed", device_id);
+    const long long dense = (long long)b * k_in;
+    if ((idx_list_stride != 0 && idx_list_stride < dense) || (score_list_stride != 0 && score_list_stride < dense))
+        return fail(MTR_ERR_INVALID, "list strides must be 0 (dense) or at least b*k_in");
     HIP_TRY(mtr::launch_merge_topk(dev_score, nullptr, reinterpret_cast<const long long*>(dev_idx), n_lists,
-                                   (long long)b * k_in, (long long)k_in, k_in, b, k_out, 0,
+                                   idx_list_stride ? idx_list_stride : dense,
+                                   score_list_stride ? score_list_stride : dense, (long long)k_in, k_in, b, k_out, 0,
                                    reinterpret_cast<long long*>(dev_out_idx), dev_out_score,
                                    static_cast<hipStream_t>(stream)));
     return MTR_OK;

@@ -73,10 +73,11 @@ hipError_t launch_scan_topk(const void* rows, int dtype, int64_t n, int ld, int 
 
 // Candidate merge: for each of b queries, the best k_out of n_lists * k_in
 // candidates.  Candidate (list l, query q, slot j) sits at
-// l*list_stride + q*query_stride + j.  idx32 != NULL: 32-bit local rows, to
+// l*list_stride + q*query_stride + j (list_stride_s for the scores).  idx32 != NULL: 32-bit local rows, to
 // which idx_offset is added; else idx64.  Entries with id < 0 are padding.
 hipError_t launch_merge_topk(const float* cand_s, const int* idx32, const long long* idx64,
-                             int n_lists, long long list_stride, long long query_stride, int k_in,
+                             int n_lists, long long list_stride, long long list_stride_s,
+                             long long query_stride, int k_in,
                              int b, int k_out, long long idx_offset, long long* out_idx,
                              float* out_score, hipStream_t stream);
 

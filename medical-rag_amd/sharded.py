@@ -28,57 +28,86 @@ def shard_bounds(n_rows: int, world_size: int, rank: int):
     return lo, hi
 
 
-def pack_candidates(idx, score):
-    """(B, k) int64 ids + (B, k) float32 scores -> one (B*k*3,) int32 buffer
-    [ids as int32 pairs | score bits], the unit the all-gather moves."""
-    import torch
-    b, k = idx.shape
-    buf = torch.empty(b * k * 3, dtype=torch.int32, device=idx.device)
-    buf[: 2 * b * k].view(torch.int64).view(b, k).copy_(idx)
-    buf[2 * b * k:].view(torch.float32).view(b, k).copy_(score)
-    return buf
+class CandidateBlock:
+    """One rank's (B, k) candidates in a single buffer, the unit the all-gather
+    moves: B*k int64 ids, then B*k float32 scores, padded to whole int64 words.
+    `ids` and `scores` are views, so the search kernel writes straight into the
+    send buffer and the merge kernel reads straight out of the gathered one."""
+
+    def __init__(self, b: int, k: int, device, n_blocks: int = 1):
+        import torch
+        self.b, self.k, self.n_blocks = b, k, n_blocks
+        self.words = b * k + (b * k + 1) // 2           # int64 words per block
+        self.buf = torch.zeros((n_blocks, self.words), dtype=torch.int64, device=device)
+        self.ids = self.buf[:, : b * k].view(n_blocks, b, k)
+        self.scores = self.buf.view(torch.float32).view(n_blocks, 2 * self.words)[:, 2 * b * k: 3 * b * k] \
+            .view(n_blocks, b, k)
 
 
 def gather_candidates(idx, score, group=None):
     """All-gather of every rank's (B, k) candidates.  Returns (ids (W, B, k)
-    int64, scores (W, B, k) float32) on the caller's device.  Works on GPU
-    tensors over RCCL (backend "nccl") and on CPU tensors over gloo."""
-    import torch
+    int64, scores (W, B, k) float32) views of one gathered buffer on the
+    caller's device.  Works on GPU tensors over RCCL (backend "nccl") and on CPU
+    tensors over gloo."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
     b, k = idx.shape
-    mine = pack_candidates(idx.contiguous(), score.contiguous())
-    out = torch.empty((world, mine.numel()), dtype=torch.int32, device=mine.device)
+    mine = CandidateBlock(b, k, idx.device)
+    mine.ids[0].copy_(idx)
+    mine.scores[0].copy_(score)
+    everyone = CandidateBlock(b, k, idx.device, n_blocks=world)
+    exchange(mine, everyone, group)
+    return everyone.ids, everyone.scores
+
+
+def exchange(mine: CandidateBlock, everyone: CandidateBlock, group=None):
+    import torch.distributed as dist
     if dist.get_backend(group) == "gloo":
-        parts = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(parts, mine, group=group)
-        out = torch.stack(parts)
+        parts = [everyone.buf[r] for r in range(everyone.n_blocks)]
+        dist.all_gather(parts, mine.buf[0], group=group)
     else:
-        dist.all_gather_into_tensor(out, mine, group=group)
-    ids = out[:, : 2 * b * k].contiguous().view(torch.int64).view(world, b, k)
-    scores = out[:, 2 * b * k:].contiguous().view(torch.float32).view(world, b, k)
-    return ids, scores
+        dist.all_gather_into_tensor(everyone.buf, mine.buf, group=group)
 
 
 class ShardedIndex:
     """This rank's shard plus the process group it searches with."""
 
-    def __init__(self, shard, group=None):
+    def __init__(self, shard, group=None, always_exchange=False):
         self.shard = shard
         self.group = group
+        # always_exchange: run the all-gather + merge even on a single rank (a
+        # rehearsal of the multi-GPU path on one GPU).
+        self.always_exchange = always_exchange
+        self._bufs = {}
 
     @property
     def world_size(self):
         import torch.distributed as dist
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
 
+    def _buffers(self, b, k, device):
+        import torch
+        key = (b, k, str(device))
+        hit = self._bufs.get(key)
+        if hit is None:
+            hit = (CandidateBlock(b, k, device), CandidateBlock(b, k, device, n_blocks=self.world_size),
+                   torch.empty((b, k), dtype=torch.int64, device=device),
+                   torch.empty((b, k), dtype=torch.float32, device=device))
+            self._bufs[key] = hit
+        return hit
+
     def search_device(self, queries, k: int = 10, metric: str = "cosine"):
         """queries: (B, d) GPU tensor, identical on every rank.  Returns the
         global (ids (B, k) int64, scores (B, k) float32) on every rank,
-        enqueued on torch's current stream."""
+        enqueued on torch's current stream.  The returned tensors are reused
+        by the next call with the same (B, k)."""
         from . import _native
-        idx, score = self.shard.search_device(queries, k=k, metric=metric)
-        if self.world_size == 1:
-            return idx, score
-        ids, scores = gather_candidates(idx, score, self.group)
-        return _native.merge_topk_device(ids, scores, k)
+        if queries.dim() == 1:
+            queries = queries[None, :]
+        b = queries.shape[0]
+        mine, everyone, out_i, out_s = self._buffers(b, k, queries.device)
+        if self.world_size == 1 and not self.always_exchange:
+            return self.shard.search_device(queries, k=k, metric=metric, out=(out_i, out_s))
+        self.shard.search_device(queries, k=k, metric=metric, out=(mine.ids[0], mine.scores[0]))
+        exchange(mine, everyone, self.group)
+        return _native.merge_topk_device(everyone.ids, everyone.scores, k, out=(out_i, out_s))

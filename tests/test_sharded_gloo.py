@@ -27,14 +27,21 @@ def test_shard_bounds_cover_rows_exactly():
         shard_bounds(10, 2, 2)
 
 
-def test_pack_round_trip():
-    from medical_rag_amd.sharded import pack_candidates
-    idx = torch.tensor([[5, -1, 2 ** 40 + 3], [7, 8, 9]], dtype=torch.int64)
-    score = torch.tensor([[0.5, float("-inf"), -2.0], [1.0, 0.25, 0.125]], dtype=torch.float32)
-    buf = pack_candidates(idx, score)
-    assert buf.dtype == torch.int32 and buf.numel() == 2 * 3 * 3
-    assert torch.equal(buf[:12].view(torch.int64).view(2, 3), idx)
-    assert torch.equal(buf[12:].view(torch.float32).view(2, 3), score)
+def test_candidate_block_views():
+    from medical_rag_amd.sharded import CandidateBlock
+    for b, k in ((2, 3), (1, 1), (5, 10)):
+        blk = CandidateBlock(b, k, "cpu", n_blocks=3)
+        assert blk.buf.shape == (3, b * k + (b * k + 1) // 2) and blk.buf.dtype == torch.int64
+        idx = torch.arange(3 * b * k, dtype=torch.int64).view(3, b, k) * (2 ** 33) - 1
+        score = torch.linspace(-2, 2, 3 * b * k, dtype=torch.float32).view(3, b, k)
+        score[0, 0, 0] = float("-inf")
+        blk.ids.copy_(idx)
+        blk.scores.copy_(score)
+        # ids and scores do not overlap and survive a raw copy of the buffer
+        clone = CandidateBlock(b, k, "cpu", n_blocks=3)
+        clone.buf.copy_(blk.buf)
+        assert torch.equal(clone.ids, idx) and torch.equal(clone.scores, score)
+        assert clone.ids.stride(0) == blk.words and clone.scores.stride(0) == 2 * blk.words
 
 
 def _worker(rank, world, port, ret):
