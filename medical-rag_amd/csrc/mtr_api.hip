@@ -98,6 +98,7 @@ struct mtr_index {
     DevBuf cand_s, cand_i;
     DevBuf q_bf16;     // bf16 query tiles for the matrix-core kernel
     DevBuf mfma_cand;  // its workgroups' candidate buffers
+    DevBuf mfma_floor; // per-query floor shared by the row ranges
     DevBuf out_i, out_s;
     DevBuf stage;      // staging for host rows
     void* pinned = nullptr;
@@ -141,6 +142,9 @@ int enqueue_mfma(mtr_index* ix, const mtr::MfmaPlan& plan, const void* dev_queri
     if ((rc = ix->mfma_cand.reserve(plan.cand_bytes)) != MTR_OK) return rc;
     if ((rc = ix->cand_s.reserve((size_t)b * plan.n_ranges * k * 4)) != MTR_OK) return rc;
     if ((rc = ix->cand_i.reserve((size_t)b * plan.n_ranges * k * 4)) != MTR_OK) return rc;
+    const size_t floor_bytes = (size_t)plan.n_qtiles * 128 * 4;
+    if ((rc = ix->mfma_floor.reserve(floor_bytes)) != MTR_OK) return rc;
+    HIP_TRY(hipMemsetAsync(ix->mfma_floor.p, 0, floor_bytes, stream));
     HIP_TRY(hipMemsetAsync(ix->q_bf16.p, 0, qbytes, stream));
     HIP_TRY(mtr::launch_load_rows(dev_queries, q_dtype, b, ix->d, ix->q_bf16.p, MTR_BF16, ix->ld,
                                   metric == MTR_COSINE ? 1 : 0, ix->flag, stream));
@@ -158,7 +162,7 @@ int enqueue_mfma(mtr_index* ix, const mtr::MfmaPlan& plan, const void* dev_queri
         HIP_TRY(hipEventRecord(e0, stream));
     }
     HIP_TRY(mtr::launch_score_mfma(ix->rows, ix->n, ix->ld, ix->q_bf16.p, b, k, plan, ix->mfma_cand.p,
-                                   static_cast<float*>(ix->cand_s.p), static_cast<int*>(ix->cand_i.p), stream));
+                                   static_cast<unsigned int*>(ix->mfma_floor.p), static_cast<float*>(ix->cand_s.p), static_cast<int*>(ix->cand_i.p), stream));
     if (ix->profiling) HIP_TRY(hipEventRecord(e1, stream));
     HIP_TRY(mtr::launch_merge_topk(static_cast<const float*>(ix->cand_s.p), static_cast<const int*>(ix->cand_i.p),
                                    nullptr, plan.n_ranges, (long long)k, (long long)k, (long long)plan.n_ranges * k, k, b, k,
@@ -463,6 +467,7 @@ void mtr_index_destroy(mtr_index_t* ix) {
         ix->cand_i.release();
         ix->q_bf16.release();
         ix->mfma_cand.release();
+        ix->mfma_floor.release();
         ix->out_i.release();
         ix->out_s.release();
         ix->stage.release();

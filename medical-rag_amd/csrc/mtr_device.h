@@ -83,6 +83,7 @@ hipError_t launch_merge_topk(const float* cand_s, const int* idx32, const long l
 
 struct MfmaPlan {
     int cap;                  // candidate slots per (workgroup, query): 256 or 512
+    int slack;                // extra keys an in-loop re-selection may keep
     int n_qtiles;             // query tiles of 128
     int n_ranges;             // row ranges (= candidate lists per query)
     long long tiles_per_range;
@@ -96,9 +97,11 @@ struct MfmaPlan {
 int plan_mfma(int64_t n, int ld, int b, int k, int num_cus, MfmaPlan* plan);
 
 // bf16 rows x bf16 queries on the matrix cores with fused top-k.  queries_bf16:
-// [n_qtiles*128][ld], rows past b zero.  Outputs [b][n_ranges][k] candidate
+// [n_qtiles*128][ld], rows past b zero.  shared_floor: n_qtiles*128 words, zeroed by the
+// caller before every launch.  Outputs [b][n_ranges][k] candidate
 // lists (unsorted, padded with (-inf, -1)).
 hipError_t launch_score_mfma(const void* rows, int64_t n, int ld, const void* queries_bf16, int b, int k,
-                             const MfmaPlan& plan, void* cand_buf, float* out_s, int* out_i, hipStream_t stream);
+                             const MfmaPlan& plan, void* cand_buf, unsigned int* shared_floor, float* out_s,
+                             int* out_i, hipStream_t stream);
 
 }  // namespace mtr

@@ -35,6 +35,9 @@
 // the ranges.
 //
 // Algorithmic work per launch: 2 * B * n * d flops (bf16 MFMA, fp32 accumulate).
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "mtr_device.h"
 #include "wave_select.h"
 
@@ -63,7 +66,12 @@ struct MfmaArgs {
     int n_ranges;
     long long tiles_per_range;
     int k;
+    int slack;               // extra keys an in-loop re-selection may keep
+    int debug_no_candidates;       // timing experiments only: bit 0 every floor starts at +inf; bit 1 appends wrap, no re-selection; bit 2 count events
+    unsigned long long* debug_counters;  // [0] appends [1] re-selections (bit 2)
+    float debug_floor;                   // bit 4: every own floor starts here
     unsigned long long* cand_buf;  // [grid][TN][CAP]
+    unsigned int* shared_floor;    // [n_qtiles*TN] order-preserving score bits, zeroed before the launch
     float* out_s;            // [b][n_ranges][k]
     int* out_i;
 };
@@ -88,18 +96,26 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds, int row, int chunk)
     return *reinterpret_cast<const bf16x8*>(lds + row * 128 + ((chunk ^ (row & 7)) << 4));
 }
 
-// Re-selects the k best keys of one query's buffer (c entries, c <= 64*E),
-// compacts them to the front, and publishes the new count and floor.
+// Re-selection of one query's buffer.
+//   load_keys:      c entries (c <= 64*E) into registers, 0 for empty slots.
+//   finish_select:  keeps between k and k + slack of them, compacted to the
+//                   front, and publishes the new count and floors.
 template <int E>
-__device__ __forceinline__ void compact_query(unsigned long long* buf, int c, int k, float* floor_lds, int* cnt_lds,
-                                              int q, int lane) {
-    unsigned long long key[E];
+__device__ __forceinline__ void load_keys(const unsigned long long* buf, int c, int lane,
+                                          unsigned long long (&key)[E]) {
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int i = e * 64 + lane;
         key[e] = i < c ? buf[i] : 0ull;
     }
-    const unsigned long long cut = wave_kth_largest<E>(key, k);
+}
+
+template <int E>
+__device__ __forceinline__ void finish_select(unsigned long long* buf, const unsigned long long (&key)[E], int k,
+                                              int slack, float* floor_lds, int* cnt_lds, int q, int lane,
+                                              unsigned int* shared_floor_q, unsigned int* hist) {
+    int passes = 0;
+    const unsigned long long cut = wave_kth_largest_hist<E>(key, k, slack, hist, lane, &passes);
     int base = 0;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -111,17 +127,37 @@ __device__ __forceinline__ void compact_query(unsigned long long* buf, int c, in
     }
     if (lane == 0) {
         cnt_lds[q] = base;
-        if (cut != 0ull) floor_lds[q] = key_score(cut);
+        if (cut != 0ull) {
+            const unsigned int hi = (unsigned int)(cut >> 32);
+            // Own floor (tested with ">"): the exact k-th best score once all four
+            // score bytes are decided, else the largest value below the kept bin.
+            floor_lds[q] = unorder_f32(passes >= 4 ? hi : hi - 1u);
+            // At least k rows of this range score >= hi, so no row below it can be in
+            // the query's overall top-k: tell the other row ranges.
+            atomicMax(shared_floor_q, hi);
+        }
     }
+}
+
+template <int E>
+__device__ __forceinline__ void compact_query(unsigned long long* buf, int c, int k, int slack, float* floor_lds,
+                                              int* cnt_lds, int q, int lane, unsigned int* shared_floor_q,
+                                              unsigned int* hist) {
+    unsigned long long key[E];
+    load_keys<E>(buf, c, lane, key);
+    finish_select<E>(buf, key, k, slack, floor_lds, cnt_lds, q, lane, shared_floor_q, hist);
 }
 
 template <int CAP>
 __global__ __launch_bounds__(kThreads, 2) void score_topk_mfma_kernel(MfmaArgs a) {
     constexpr int E = CAP / 64;
+    static_assert((CAP & (CAP - 1)) == 0, "CAP must be a power of two");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const stage0 = smem;
-    float* floor_lds = reinterpret_cast<float*>(smem + 2 * kStageBytes);
+    float* floor_lds = reinterpret_cast<float*>(smem + 2 * kStageBytes);  // own k-th best score (strict)
     int* cnt_lds = reinterpret_cast<int*>(floor_lds + TN);
+    float* shared_lds = reinterpret_cast<float*>(cnt_lds + TN);           // best floor of ANY range (non-strict)
+    unsigned int* hist_lds = reinterpret_cast<unsigned int*>(shared_lds + TN) + (threadIdx.x >> 6) * 256;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -146,9 +182,14 @@ __global__ __launch_bounds__(kThreads, 2) void score_topk_mfma_kernel(MfmaArgs a
 
     for (int i = tid; i < TN; i += kThreads) {
         const int qg = qt * TN + i;
-        floor_lds[i] = qg < a.b ? -__builtin_huge_valf() : __builtin_huge_valf();  // padding queries collect nothing
+        // padding queries collect nothing; the timing-only debug mode collects nothing at all
+        floor_lds[i] = (qg < a.b && !(a.debug_no_candidates & 1)) ? ((a.debug_no_candidates & 16) ? a.debug_floor : -__builtin_huge_valf())
+                                                                 : __builtin_huge_valf();
         cnt_lds[i] = 0;
+        shared_lds[i] = -__builtin_huge_valf();
     }
+    unsigned int* shared_floor = a.shared_floor + (size_t)qt * TN;
+    unsigned int pending_floor = 0;  // threads < TN: the shared floor word fetched at the start of a tile
     unsigned long long* my_buf = a.cand_buf + (size_t)blockIdx.x * TN * CAP;
     const bf16_t* qbase = a.queries + (size_t)qt * TN * a.ld;
 
@@ -171,6 +212,8 @@ __global__ __launch_bounds__(kThreads, 2) void score_topk_mfma_kernel(MfmaArgs a
     int ks = 0;
     for (long long s = 0; s < total_steps; ++s) {
         const int cur = (int)(s & 1);
+        if (ks == 0 && tid < TN)
+            pending_floor = __hip_atomic_load(shared_floor + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (s + 1 < total_steps) {
             const int nks = ks + 1 == ksteps ? 0 : ks + 1;
             const long long ntile = ks + 1 == ksteps ? tile + 1 : tile;
@@ -198,24 +241,51 @@ __global__ __launch_bounds__(kThreads, 2) void score_topk_mfma_kernel(MfmaArgs a
         if (tile_done) {
             // Scores of 128 rows x 128 queries are complete: append what clears each query's floor.
             const long long row_base = tile * TM + wm * 64 + 4 * (lane >> 5);
+            const bool last_tile = (tile + 1) * TM > a.n;
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
                 const int ql = wn * 64 + n * 32 + (lane & 31);
-                const float fl = floor_lds[ql];
+                // "v > own floor && v >= shared floor" as ONE strict threshold: v >= sh is
+                // v > (largest float below sh); a NaN from sh = -inf loses the fmaxf.
+                const float thr = fmaxf(floor_lds[ql], unorder_f32(order_f32(shared_lds[ql]) - 1u));
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
                     float mx = acc[m][n][0];
 #pragma unroll
                     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[m][n][r]);
-                    if (__any(mx > fl)) {
-                        if (mx > fl) {
+                    if (__any(mx > thr)) {
+                        const long long row0 = row_base + m * 32;
+                        unsigned int pass = 0;
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) {
-                                const float v = acc[m][n][r];
-                                const long long row = row_base + m * 32 + (r & 3) + 8 * (r >> 2);
-                                if (v > fl && row < a.n) {
-                                    const int slot = atomicAdd(&cnt_lds[ql], 1);
-                                    my_buf[(size_t)ql * CAP + slot] = pack_key(v, (int)row);
+                        for (int r = 0; r < 16; ++r) pass |= (acc[m][n][r] > thr) ? (1u << r) : 0u;
+                        if (last_tile) {  // only the last tile of the matrix can hold rows past its end
+#pragma unroll
+                            for (int r = 0; r < 16; ++r)
+                                if (row0 + (r & 3) + 8 * (r >> 2) >= a.n) pass &= ~(1u << r);
+                        }
+                        // One LDS atomic per lane reserves all its slots at once (a
+                        // returning atomic per element would serialise on LDS latency).
+                        int slot = 0;
+                        if (pass) {
+                            const int np = __popc(pass);
+                            slot = atomicAdd(&cnt_lds[ql], np);
+                            if (a.debug_no_candidates & 4) atomicAdd(a.debug_counters, (unsigned long long)np);
+                        }
+                        // Registers any lane wants to store, as a wave-uniform mask: the
+                        // sixteen tests below are then scalar branches.
+                        unsigned int any_r = pass;
+#pragma unroll
+                        for (int off = 32; off >= 1; off >>= 1) any_r |= __shfl_xor(any_r, off, 64);
+                        any_r = __builtin_amdgcn_readfirstlane(any_r);
+                        unsigned long long* dst = my_buf + (size_t)ql * CAP;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            if (any_r & (1u << r)) {
+                                if (pass & (1u << r)) {
+                                    if (a.debug_no_candidates & 2) slot &= CAP - 1;
+                                    if (slot < CAP)
+                                        dst[slot] = pack_key(acc[m][n][r], (int)(row0 + (r & 3) + 8 * (r >> 2)));
+                                    ++slot;
                                 }
                             }
                         }
@@ -229,14 +299,18 @@ __global__ __launch_bounds__(kThreads, 2) void score_topk_mfma_kernel(MfmaArgs a
         if (tile_done) {
             // Wave w looks after queries [32w, 32w+32): re-select any whose buffer
             // could overflow on the next tile (a tile adds at most TM entries).
+            if (tid < TN) shared_lds[tid] = unorder_f32(pending_floor | (pending_floor == 0 ? 0x007fffffu : 0u));
             const int c = cnt_lds[wave * 32 + (lane & 31)];
-            unsigned long long need = __ballot(lane < 32 && c + TM > CAP);
+            unsigned long long need = __ballot(lane < 32 && c + TM > CAP);  // k + slack + TM <= CAP by plan
+            if (a.debug_no_candidates & 2) need = 0;
+            if ((a.debug_no_candidates & 4) && lane == 0 && need) atomicAdd(a.debug_counters + 1, (unsigned long long)__popcll(need));
             while (need) {
                 const int j = __ffsll((long long)need) - 1;
                 need &= need - 1;
                 const int q = wave * 32 + j;
                 const int cq = __builtin_amdgcn_readfirstlane(cnt_lds[q]);
-                compact_query<E>(my_buf + (size_t)q * CAP, cq, a.k, floor_lds, cnt_lds, q, lane);
+                compact_query<E>(my_buf + (size_t)q * CAP, cq, a.k, a.slack, floor_lds, cnt_lds, q, lane,
+                                 shared_floor + q, hist_lds);
             }
             ks = 0;
             ++tile;
@@ -255,7 +329,7 @@ __global__ __launch_bounds__(kThreads, 2) void score_topk_mfma_kernel(MfmaArgs a
         int cq = __builtin_amdgcn_readfirstlane(cnt_lds[q]);
         unsigned long long* buf = my_buf + (size_t)q * CAP;
         if (cq > a.k) {
-            compact_query<E>(buf, cq, a.k, floor_lds, cnt_lds, q, lane);
+            compact_query<E>(buf, cq, a.k, 0, floor_lds, cnt_lds, q, lane, shared_floor + q, hist_lds);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -281,6 +355,12 @@ __global__ __launch_bounds__(kThreads, 2) void score_topk_mfma_kernel(MfmaArgs a
 int plan_mfma(int64_t n, int ld, int b, int k, int num_cus, MfmaPlan* plan) {
     if (ld % BK != 0 || k < 1 || k > 256 || b < 1 || n < 1) return -1;
     plan->cap = k <= 32 ? 256 : 512;
+    if (const char* e = getenv("MTR_MFMA_CAP")) {
+        const int c = atoi(e);
+        if ((c == 256 || c == 512) && k + 128 <= c) plan->cap = c;
+    }
+    plan->slack = (plan->cap - 128 - k) / 4;
+    if (plan->slack > 64) plan->slack = 64;
     plan->n_qtiles = (b + TN - 1) / TN;
     const long long n_tiles = (n + TM - 1) / TM;
     long long ranges = (2LL * num_cus + plan->n_qtiles - 1) / plan->n_qtiles;
@@ -289,13 +369,14 @@ int plan_mfma(int64_t n, int ld, int b, int k, int num_cus, MfmaPlan* plan) {
     plan->tiles_per_range = (n_tiles + ranges - 1) / ranges;
     plan->n_ranges = (int)((n_tiles + plan->tiles_per_range - 1) / plan->tiles_per_range);
     plan->grid = plan->n_qtiles * plan->n_ranges;
-    plan->lds = 2 * kStageBytes + TN * 8;
+    plan->lds = 2 * kStageBytes + TN * 12 + (kThreads / 64) * 1024;
     plan->cand_bytes = (size_t)plan->grid * TN * plan->cap * 8;
     return 0;
 }
 
 hipError_t launch_score_mfma(const void* rows, int64_t n, int ld, const void* queries_bf16, int b, int k,
-                             const MfmaPlan& plan, void* cand_buf, float* out_s, int* out_i, hipStream_t stream) {
+                             const MfmaPlan& plan, void* cand_buf, unsigned int* shared_floor, float* out_s,
+                             int* out_i, hipStream_t stream) {
     MfmaArgs a;
     a.rows = static_cast<const bf16_t*>(rows);
     a.n = n;
@@ -306,7 +387,21 @@ hipError_t launch_score_mfma(const void* rows, int64_t n, int ld, const void* qu
     a.n_ranges = plan.n_ranges;
     a.tiles_per_range = plan.tiles_per_range;
     a.k = k;
+    a.slack = plan.slack;
+    a.debug_no_candidates = getenv("MTR_MFMA_DEBUG") ? atoi(getenv("MTR_MFMA_DEBUG")) : 0;
+    a.debug_counters = nullptr;
+    a.debug_floor = getenv("MTR_MFMA_DEBUG_FLOOR") ? (float)atof(getenv("MTR_MFMA_DEBUG_FLOOR")) : 0.f;
+    if (a.debug_no_candidates & 4) {
+        static unsigned long long* counters = nullptr;
+        if (!counters && hipMalloc(reinterpret_cast<void**>(&counters), 16) != hipSuccess) return hipErrorOutOfMemory;
+        unsigned long long host[2] = {0, 0};
+        (void)hipMemcpy(host, counters, 16, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[mtr debug] previous launch: appends=%llu re-selections=%llu\n", host[0], host[1]);
+        (void)hipMemset(counters, 0, 16);
+        a.debug_counters = counters;
+    }
     a.cand_buf = static_cast<unsigned long long*>(cand_buf);
+    a.shared_floor = shared_floor;
     a.out_s = out_s;
     a.out_i = out_i;
     hipError_t e;

@@ -67,4 +67,71 @@ __device__ __forceinline__ unsigned long long wave_kth_largest(const unsigned lo
     return ((unsigned long long)hp << 32) | lp;
 }
 
+// Histogram form of the same selection: eight passes of 8 key bits, most
+// significant first.  Each pass counts the still-undecided keys per byte value
+// in a 256-word LDS histogram (`hist`, private to the wave), finds the byte
+// value that holds the k-th largest, and narrows to it.
+//
+// slack > 0 allows an early stop: as soon as keeping the whole current bin
+// would keep at most k + slack keys, the cut is the bin's lower bound.
+// Returns the cut (keep keys >= cut; 0 when there are at most k keys);
+// *passes_done tells how many key bytes of the cut are exact.
+template <int E>
+__device__ __forceinline__ unsigned long long wave_kth_largest_hist(const unsigned long long (&key)[E], int k,
+                                                                    int slack, unsigned int* hist, int lane,
+                                                                    int* passes_done) {
+    bool act[E];
+    int nact = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        act[e] = key[e] != 0ull;
+        nact += __popcll(__ballot(act[e]));
+    }
+    *passes_done = 8;
+    if (nact <= k) return 0ull;
+    int need = k;
+    unsigned long long prefix = 0ull;
+    using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+    for (int pass = 0; pass < 8; ++pass) {
+        const int shift = 56 - 8 * pass;
+        reinterpret_cast<u32x4*>(hist)[lane] = u32x4{0u, 0u, 0u, 0u};
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+            if (act[e]) atomicAdd(&hist[(unsigned int)(key[e] >> shift) & 255u], 1u);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const u32x4 h = reinterpret_cast<const u32x4*>(hist)[lane];  // bins 4*lane .. 4*lane+3
+        const unsigned int mine = h[0] + h[1] + h[2] + h[3];
+        unsigned int incl = mine;  // inclusive sum over lanes >= this one (higher lanes hold higher bins)
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned int t = __shfl_down(incl, off, 64);
+            if (lane + off < 64) incl += t;
+        }
+        const unsigned int a3 = incl - mine, a2 = a3 + h[3], a1 = a2 + h[2], a0 = a1 + h[1];
+        const unsigned int un = (unsigned int)need;
+        int bin = -1;
+        unsigned int above = 0, count = 0;
+        if (a3 < un && un <= a3 + h[3]) { bin = 4 * lane + 3; above = a3; count = h[3]; }
+        else if (a2 < un && un <= a2 + h[2]) { bin = 4 * lane + 2; above = a2; count = h[2]; }
+        else if (a1 < un && un <= a1 + h[1]) { bin = 4 * lane + 1; above = a1; count = h[1]; }
+        else if (a0 < un && un <= a0 + h[0]) { bin = 4 * lane; above = a0; count = h[0]; }
+        const unsigned long long who = __ballot(bin >= 0);  // exactly one lane
+        const int src = __ffsll((long long)who) - 1;
+        const unsigned int b = (unsigned int)__builtin_amdgcn_readlane(bin, src);
+        need -= __builtin_amdgcn_readlane((int)above, src);
+        nact = __builtin_amdgcn_readlane((int)count, src);
+        prefix |= (unsigned long long)b << shift;
+#pragma unroll
+        for (int e = 0; e < E; ++e) act[e] = act[e] && (((unsigned int)(key[e] >> shift) & 255u) == b);
+        if (nact - need <= slack) {
+            *passes_done = pass + 1;
+            break;
+        }
+    }
+    return prefix;
+}
+
 }  // namespace mtr
