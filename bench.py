@@ -12,6 +12,7 @@ all-gather of the per-rank candidates and the k-way merge.
 Workloads (BASELINE.json configs):
     c4  10M x 1024 bf16, B=1, top-10   (default: the north-star headline shape)
     c2   1M x  768 fp32, B=1, top-10   (HBM-bound GEMV regime)
+    c3   1M x 1024 bf16, B=4096, top-100 (matrix-core regime)
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -67,6 +68,24 @@ def build_shard(native, torch, lo, hi, dim, store, device, needles, queries, k):
         shard.load_device(a - lo, part.contiguous())
         del block, part
     return shard
+
+
+def pmc_traffic(workload, default_shape):
+    """HBM-side bytes per scoring launch from the committed rocprofv3 PMC passes
+    (profiles/*pmc_traffic.json, newest round first); None when the run is not
+    the profiled shape."""
+    import glob
+    if not default_shape:
+        return None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                rec = json.load(f).get(workload)
+        except (OSError, ValueError):
+            continue
+        if rec:
+            return rec["traffic_bytes_per_launch"]
+    return None
 
 
 def cpu_baseline(dim, k, full_rows, budget_s=12.0):
@@ -201,16 +220,18 @@ def main():
         local_bytes = (hi - lo) * dim * esize  # algorithmic bytes of one scan launch on this rank
         achieved = local_bytes / (scan_avg_ms * 1e-3) / 1e9
         passes = n_launch / args.steps
+        default_shape = world == 1 and not (args.rows or args.batch or args.k)
+        traffic = pmc_traffic(args.workload, default_shape)
         if batch >= 17 and store == "bf16":  # the matrix-core kernel served this batch
             flops = 2.0 * batch * (hi - lo) * dim
             tf = flops / (scan_avg_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": tf / MFMA_PEAK_TFLOPS, "traffic": None, "kernel": "score_topk_mfma_kernel",
+                    "frac": tf / MFMA_PEAK_TFLOPS, "traffic": traffic, "kernel": "score_topk_mfma_kernel",
                     "kernel_avg_ms": scan_avg_ms, "launches_per_step": passes,
                     "algorithmic_flops_per_launch": flops}
         else:
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "kernel": "scan_topk_kernel", "kernel_avg_ms": scan_avg_ms,
                     "launches_per_step": passes, "algorithmic_bytes_per_launch": local_bytes}
         res = {

@@ -76,6 +76,7 @@ struct MfmaArgs {
     int* out_i;
 };
 
+template <int AUX>
 __device__ __forceinline__ void stage_tile(const bf16_t* base, long long row0, long long row_max, int ld, int k0,
                                            char* lds, int wave, int lane) {
     // 128 rows x 128 bytes.  One wave instruction fills 8 rows; lane L writes
@@ -88,7 +89,7 @@ __device__ __forceinline__ void stage_tile(const bf16_t* base, long long row0, l
         row = row < row_max ? row : row_max;
         const int chunk = (lane & 7) ^ (lane >> 3);
         const bf16_t* src = base + row * ld + k0 + chunk * 8;
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(lds + t * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(lds + t * 1024), 16, 0, AUX);
     }
 }
 
@@ -148,7 +149,7 @@ __device__ __forceinline__ void compact_query(unsigned long long* buf, int c, in
     finish_select<E>(buf, key, k, slack, floor_lds, cnt_lds, q, lane, shared_floor_q, hist);
 }
 
-template <int CAP>
+template <int CAP, int ROW_AUX>
 __global__ __launch_bounds__(kThreads, 2) void score_topk_mfma_kernel(MfmaArgs a) {
     constexpr int E = CAP / 64;
     static_assert((CAP & (CAP - 1)) == 0, "CAP must be a power of two");
@@ -203,8 +204,8 @@ __global__ __launch_bounds__(kThreads, 2) void score_topk_mfma_kernel(MfmaArgs a
 
     const long long total_steps = my_tiles * ksteps;
     if (total_steps > 0) {
-        stage_tile(a.rows, tile_lo * TM, a.n - 1, a.ld, 0, stage0, wave, lane);
-        stage_tile(qbase, 0, TN - 1, a.ld, 0, stage0 + TM * BK * 2, wave, lane);
+        stage_tile<ROW_AUX>(a.rows, tile_lo * TM, a.n - 1, a.ld, 0, stage0, wave, lane);
+        stage_tile<0>(qbase, 0, TN - 1, a.ld, 0, stage0 + TM * BK * 2, wave, lane);
     }
     __syncthreads();
 
@@ -217,8 +218,8 @@ __global__ __launch_bounds__(kThreads, 2) void score_topk_mfma_kernel(MfmaArgs a
         if (s + 1 < total_steps) {
             const int nks = ks + 1 == ksteps ? 0 : ks + 1;
             const long long ntile = ks + 1 == ksteps ? tile + 1 : tile;
-            stage_tile(a.rows, ntile * TM, a.n - 1, a.ld, nks * BK, stage0 + (cur ^ 1) * kStageBytes, wave, lane);
-            stage_tile(qbase, 0, TN - 1, a.ld, nks * BK, stage0 + (cur ^ 1) * kStageBytes + TM * BK * 2, wave, lane);
+            stage_tile<ROW_AUX>(a.rows, ntile * TM, a.n - 1, a.ld, nks * BK, stage0 + (cur ^ 1) * kStageBytes, wave, lane);
+            stage_tile<0>(qbase, 0, TN - 1, a.ld, nks * BK, stage0 + (cur ^ 1) * kStageBytes + TM * BK * 2, wave, lane);
         }
         const char* sa = stage0 + cur * kStageBytes;
         const char* sb = stage0 + cur * kStageBytes + TM * BK * 2;
@@ -404,19 +405,22 @@ hipError_t launch_score_mfma(const void* rows, int64_t n, int ld, const void* qu
     a.shared_floor = shared_floor;
     a.out_s = out_s;
     a.out_i = out_i;
-    hipError_t e;
-    if (plan.cap == 256) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&score_topk_mfma_kernel<256>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds);
+    // Cache policy of the row-tile loads: default (0).  The non-temporal policy
+    // (aux 2, MTR_MFMA_ROW_AUX=2) measured 13-28 % slower here: every row tile
+    // is re-read through L2 by the workgroups of the other query tiles.
+    static const int row_aux = [] {
+        const char* e = getenv("MTR_MFMA_ROW_AUX");
+        return e ? atoi(e) : 0;
+    }();
+    auto launch = [&](auto kernel) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(score_topk_mfma_kernel<256>, dim3(plan.grid), dim3(kThreads), plan.lds, stream, a);
-    } else {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&score_topk_mfma_kernel<512>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(score_topk_mfma_kernel<512>, dim3(plan.grid), dim3(kThreads), plan.lds, stream, a);
-    }
-    return hipGetLastError();
+        hipLaunchKernelGGL(kernel, dim3(plan.grid), dim3(kThreads), plan.lds, stream, a);
+        return hipGetLastError();
+    };
+    if (plan.cap == 256) return row_aux == 2 ? launch(&score_topk_mfma_kernel<256, 2>) : launch(&score_topk_mfma_kernel<256, 0>);
+    return row_aux == 2 ? launch(&score_topk_mfma_kernel<512, 2>) : launch(&score_topk_mfma_kernel<512, 0>);
 }
 
 }  // namespace mtr
