@@ -12,6 +12,7 @@
 // sorted (both producers write sorted lists), which the kernel uses to find a
 // floor for the k-th best from the list heads before touching the rest.
 #include "mtr_device.h"
+#include "wave_select.h"
 #include "wave_topk.h"
 
 namespace mtr {
@@ -164,6 +165,132 @@ __global__ void merge_topk_kernel(MergeArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// Selection-based merge for 32-bit row ids and k <= 256.  Instead of inserting
+// candidates one by one, every wave packs its slice into 64-bit keys
+// (wave_select.h), finds the k-th largest with a radix walk and keeps the
+// survivors; the waves' survivor lists are then folded in rounds of
+// kFanIn-or-fewer lists per wave, and the last <= k keys are rank-sorted.
+// ---------------------------------------------------------------------------
+constexpr int kSelE = 8;                 // keys per lane: 512 slots per wave
+constexpr int kSelSlots = kSelE * 64;
+
+// Keeps the k largest of key[] (exact), writes them compacted to list[0..),
+// returns how many.
+__device__ __forceinline__ int select_into(const unsigned long long (&key)[kSelE], int k, unsigned long long* list,
+                                           unsigned int* hist, int lane) {
+    int passes = 0;
+    const unsigned long long cut = wave_kth_largest_hist<kSelE>(key, k, 0, hist, lane, &passes);
+    int base = 0;
+#pragma unroll
+    for (int e = 0; e < kSelE; ++e) {
+        const bool keep = key[e] != 0ull && key[e] >= cut;
+        const unsigned long long m = __ballot(keep);
+        if (keep) list[base + __popcll(m & ((1ull << lane) - 1ull))] = key[e];
+        base += __popcll(m);
+    }
+    return base;
+}
+
+__global__ void merge_select_kernel(MergeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nwaves = blockDim.x >> 6;
+    const int k = a.k_out;
+    unsigned long long* lists = reinterpret_cast<unsigned long long*>(smem);           // [nwaves][k]
+    unsigned int* hist_all = reinterpret_cast<unsigned int*>(lists + (size_t)nwaves * k);  // [nwaves][256]
+    int* cnt_lds = reinterpret_cast<int*>(hist_all + nwaves * 256);
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int q = blockIdx.x;
+    const long long qbase = (long long)q * a.query_stride;
+    unsigned long long* my_list = lists + (size_t)wave * k;
+    unsigned int* hist = hist_all + wave * 256;
+
+    // Level 0: each wave streams a contiguous slice of the candidates through
+    // "survivors so far + a chunk of new ones -> select k".
+    const long long total = (long long)a.n_lists * a.k_in;
+    const long long per_wave = (total + nwaves - 1) / nwaves;
+    const long long lo = wave * per_wave;
+    const long long hi = lo + per_wave < total ? lo + per_wave : total;
+    const int chunk = kSelSlots - k;  // new candidates per round (k <= 256, so >= 256)
+    int cnt = 0;
+    for (long long c0 = lo; c0 < hi; c0 += chunk) {
+        unsigned long long key[kSelE];
+#pragma unroll
+        for (int e = 0; e < kSelE; ++e) {
+            const int slot = e * 64 + lane;
+            unsigned long long v = 0ull;
+            if (slot < k) {
+                if (slot < cnt) v = my_list[slot];
+            } else {
+                const long long m = c0 + (slot - k);
+                if (m < hi) {
+                    const long long l = m / a.k_in;
+                    const long long j = m - l * a.k_in;
+                    const int id = a.ci32[l * a.list_stride + qbase + j];
+                    if (id >= 0) v = pack_key(a.cs[l * a.list_stride_s + qbase + j], id);
+                }
+            }
+            key[e] = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        cnt = select_into(key, k, my_list, hist, lane);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0) cnt_lds[wave] = cnt;
+    __syncthreads();
+
+    // Fold rounds: wave g takes lists [g*fan, g*fan + fan), all loads before any write.
+    const int fan = kSelSlots / k < 2 ? 2 : kSelSlots / k;
+    int n = nwaves;
+    while (n > 1) {
+        const int groups = (n + fan - 1) / fan;
+        unsigned long long key[kSelE];
+        const bool active = wave < groups;
+        if (active) {
+#pragma unroll
+            for (int e = 0; e < kSelE; ++e) {
+                const int slot = e * 64 + lane;
+                const int j = slot / k;          // which list of my group
+                const int i = slot - j * k;
+                const int src = wave * fan + j;
+                key[e] = (j < fan && src < n && i < cnt_lds[src]) ? lists[(size_t)src * k + i] : 0ull;
+            }
+        }
+        __syncthreads();
+        if (active) {
+            const int c = select_into(key, k, my_list, hist, lane);
+            if (lane == 0) cnt_lds[wave] = c;
+        }
+        __syncthreads();
+        n = groups;
+    }
+
+    // Rank sort of the final <= k keys (wave 0) and output.
+    if (wave == 0) {
+        const int c = cnt_lds[0];
+        float* os = a.out_s + (size_t)q * k;
+        long long* oi = a.out_i + (size_t)q * k;
+        for (int i0 = 0; i0 < k; i0 += 64) {
+            const int i = i0 + lane;
+            const unsigned long long mine = i < c ? lists[i] : 0ull;
+            int rank = 0;
+            for (int j = 0; j < c; ++j) rank += lists[j] > mine ? 1 : 0;  // LDS broadcast reads
+            if (i < c) {
+                os[rank] = key_score(mine);
+                oi[rank] = (long long)key_row(mine) + a.idx_offset;
+            }
+        }
+        for (int i = c + lane; i < k; i += 64) {
+            os[i] = -__builtin_huge_valf();
+            oi[i] = -1ll;
+        }
+    }
+}
+
 }  // namespace
 
 hipError_t launch_merge_topk(const float* cand_s, const int* idx32, const long long* idx64, int n_lists,
@@ -173,6 +300,14 @@ hipError_t launch_merge_topk(const float* cand_s, const int* idx32, const long l
     MergeArgs a{cand_s, idx32, idx64, n_lists, list_stride, list_stride_s, query_stride, k_in, k_out, idx_offset, out_idx, out_score,
                 (n_lists >= 4 * k_out && n_lists >= 128) ? 1 : 0};
     const long long total = (long long)n_lists * k_in;
+    if (idx32 && k_out <= 256 && total > 64) {
+        // one wave per 512-slot chunk of candidates, at most 16
+        long long want = (total + (kSelSlots - k_out) - 1) / (kSelSlots - k_out);
+        const int nw = (int)(want < 1 ? 1 : want > 16 ? 16 : want);
+        const size_t lds_sel = (size_t)nw * k_out * 8 + (size_t)nw * 1024 + (size_t)nw * 4 + 16;
+        hipLaunchKernelGGL(merge_select_kernel, dim3(b), dim3(nw * 64), lds_sel, stream, a);
+        return hipGetLastError();
+    }
     int nwaves = 16;
     while (nwaves > 1 && (long long)nwaves * 64 * 2 > total) nwaves /= 2;            // no idle waves on short inputs
     while (nwaves > 1 && (size_t)nwaves * k_out * 12 + kQueueCap * 12 + 128 > 60 * 1024) nwaves /= 2;  // LDS budget
