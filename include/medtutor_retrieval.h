@@ -40,7 +40,7 @@ enum {
     MTR_ERR_OOM = -5        /* device allocation failed */
 };
 
-enum { MTR_F32 = 0, MTR_F64 = 1, MTR_BF16 = 2 };
+enum { MTR_F32 = 0, MTR_F64 = 1, MTR_BF16 = 2, MTR_F16 = 3 /* mtr_pool_normalize input only */ };
 enum { MTR_COSINE = 0, MTR_IP = 1 };
 
 #define MTR_MAX_K 1024
@@ -105,6 +105,16 @@ int mtr_merge_topk_device(const int64_t* dev_idx, const float* dev_score, int32_
                           int32_t b, int32_t k_in, int32_t k_out,
                           int64_t* dev_out_idx, float* dev_out_score,
                           int32_t device_id, void* stream);
+
+/* Encoder epilogue on GPU device_id: masked mean over the t tokens of each of
+ * b sequences, then L2 normalisation (eps 1e-12), written as fp32 rows that
+ * mtr_index_search_device / mtr_index_load_rows accept directly.  dev_hidden:
+ * [b][t][d] in MTR_F32, MTR_BF16 or MTR_F16; dev_mask: [b][t] int64 (the
+ * tokenizer's attention_mask).  Enqueued on `stream`, no synchronisation.
+ * Replaces the pooling arithmetic at pipeline/utils/local_rag.py:61-65 and
+ * pipeline/utils/embed.py:68-72; the encoder forward stays in PyTorch. */
+int mtr_pool_normalize(const void* dev_hidden, int32_t dtype, const int64_t* dev_mask, int32_t b,
+                       int32_t t, int32_t d, float* dev_out, int32_t device_id, void* stream);
 
 /* Shape and storage of a shard. Any out pointer may be NULL. */
 int mtr_index_info(const mtr_index_t* index, int64_t* n, int32_t* d, int32_t* store_dtype,

@@ -15,7 +15,7 @@ LIB_NAME = "libmedtutor_retrieval.so"
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 MTR_OK, MTR_ERR_INVALID, MTR_ERR_NONFINITE, MTR_ERR_HIP, MTR_ERR_COMM, MTR_ERR_OOM = 0, -1, -2, -3, -4, -5
-MTR_F32, MTR_F64, MTR_BF16 = 0, 1, 2
+MTR_F32, MTR_F64, MTR_BF16, MTR_F16 = 0, 1, 2, 3
 MTR_COSINE, MTR_IP = 0, 1
 MTR_MAX_K = 1024
 
@@ -33,6 +33,7 @@ SIGNATURES = {
     "mtr_index_search": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "mtr_index_search_device": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "mtr_merge_topk_device": (_i32, [_vp, _vp, _i32, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
+    "mtr_pool_normalize": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _vp]),
     "mtr_index_info": (_i32, [_vp, C.POINTER(_i64), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32),
                               C.POINTER(_i32), C.POINTER(_i64)]),
     "mtr_index_read_rows": (_i32, [_vp, _i64, _i64, _vp]),
@@ -112,7 +113,8 @@ def torch_dtype_code(t) -> int:
 
 def as_host_matrix(a, name="array") -> np.ndarray:
     """C-contiguous float32/float64 2-D view of `a` (1-D becomes one row)."""
-    a = np.asarray(a)
+    if not isinstance(a, np.ndarray):
+        a = np.asarray(a)
     if a.dtype not in (np.float32, np.float64):
         a = a.astype(np.float64 if a.dtype.kind in "iu" or a.dtype.itemsize > 4 else np.float32)
     if a.ndim == 1:
@@ -272,3 +274,24 @@ def merge_topk_device(idx, score, k_out, stream=None, out=None):
                                       b, k_in, int(k_out), C.c_void_p(out_i.data_ptr()), C.c_void_p(out_s.data_ptr()),
                                       idx.device.index or 0, C.c_void_p(stream)))
     return out_i, out_s
+
+
+def pool_normalize(last_hidden_state, attention_mask, stream=None):
+    """Masked mean pooling + L2 normalisation of encoder outputs on the GPU:
+    (B, T, d) fp32/bf16/fp16 hidden states and (B, T) mask -> (B, d) float32."""
+    import torch
+    h = last_hidden_state
+    if not h.is_cuda or h.dim() != 3:
+        raise ValueError("pool_normalize wants a (B, T, d) GPU tensor")
+    codes = {torch.float32: MTR_F32, torch.bfloat16: MTR_BF16, torch.float16: MTR_F16}
+    if h.dtype not in codes:
+        raise TypeError(f"unsupported hidden-state dtype {h.dtype}")
+    h = h.contiguous()
+    m = attention_mask.to(device=h.device, dtype=torch.int64).contiguous()
+    b, t, d = h.shape
+    out = torch.empty((b, d), dtype=torch.float32, device=h.device)
+    if stream is None:
+        stream = torch.cuda.current_stream(h.device).cuda_stream
+    check(lib().mtr_pool_normalize(C.c_void_p(h.data_ptr()), codes[h.dtype], C.c_void_p(m.data_ptr()), b, t, d,
+                                   C.c_void_p(out.data_ptr()), h.device.index or 0, C.c_void_p(stream)))
+    return out

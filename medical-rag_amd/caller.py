@@ -1,0 +1,50 @@
+"""Batched form of the reference's per-case retrieval loop.
+
+The reference runs one full scan per (case, keyword)
+(pipeline/utils/retrieval.py:70-76) although every unique keyword vector exists
+before stage 1 starts (pipeline/async_main.py:193-195).  Here all distinct
+keyword vectors go through ONE search call; the per-case loop becomes a
+dictionary lookup with exactly the reference's skipping rules: keywords are
+looked up unstripped, and a missing or empty vector skips the keyword.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .local_rag import get_surrounding_pages, search
+
+
+def unique_keywords(cases) -> list:
+    """pipeline/async_main.py:193 -- stripped, non-empty string keywords of all
+    cases, de-duplicated (sorted for reproducibility; the reference iterates a set)."""
+    return sorted({kw.strip() for case in cases for kw in case.get("original_keywords", case.get("keywords", []))
+                   if isinstance(kw, str) and kw.strip()})
+
+
+def top_pages_for_keywords(kw_embeddings_map: dict, pages, top_k: int = 1) -> dict:
+    """One batched search for every keyword that has a non-empty vector:
+    keyword -> (idx (top_k,), score (top_k,))."""
+    usable = [(kw, np.asarray(v)) for kw, v in kw_embeddings_map.items() if v is not None and np.asarray(v).size > 0]
+    if not usable or len(pages) == 0:
+        return {}
+    idx, score = search(pages, np.stack([v.reshape(-1) for _, v in usable]), k=top_k)
+    return {kw: (idx[i], score[i]) for i, (kw, _) in enumerate(usable)}
+
+
+def local_pages_for_cases(cases, kw_embeddings_map: dict, pages, window_size: int = 1, hits: dict | None = None) -> list:
+    """For every case the dict the reference stores as "local_pages_per_keyword"
+    (pipeline/utils/retrieval.py:70-76, 82): keyword -> hit page with its
+    neighbours, vectors stripped."""
+    if hits is None:
+        hits = top_pages_for_keywords(kw_embeddings_map, pages, top_k=1)
+    out = []
+    for case in cases:
+        per_kw = {}
+        kws = case.get("original_keywords", case.get("keywords", []))
+        if len(pages) and kws:
+            for kw in kws:
+                hit = hits.get(kw)
+                if hit is not None:
+                    per_kw[kw] = get_surrounding_pages(int(hit[0][0]), pages, window_size)
+        out.append(per_kw)
+    return out

@@ -396,6 +396,18 @@ int mtr_merge_topk_device(const int64_t* dev_idx, const float* dev_score, int32_
     return MTR_OK;
 }
 
+int mtr_pool_normalize(const void* dev_hidden, int32_t dtype, const int64_t* dev_mask, int32_t b, int32_t t,
+                       int32_t d, float* dev_out, int32_t device_id, void* stream) {
+    if (!dev_hidden || !dev_mask || !dev_out) return fail(MTR_ERR_INVALID, "NULL argument");
+    if (dtype != MTR_F32 && dtype != MTR_BF16 && dtype != MTR_F16) return fail(MTR_ERR_INVALID, "bad dtype %d", dtype);
+    if (b < 1 || t < 1 || d < 1 || d > 8192) return fail(MTR_ERR_INVALID, "bad shape (b=%d, t=%d, d=%d)", b, t, d);
+    DeviceGuard guard(device_id);
+    if (!guard.ok) return fail(MTR_ERR_HIP, "hipSetDevice(%d) failed", device_id);
+    HIP_TRY(mtr::launch_pool_normalize(dev_hidden, dtype, reinterpret_cast<const long long*>(dev_mask), b, t, d, dev_out,
+                                       static_cast<hipStream_t>(stream)));
+    return MTR_OK;
+}
+
 int mtr_index_info(const mtr_index_t* ix, int64_t* n, int32_t* d, int32_t* store_dtype, int32_t* normalized,
                    int32_t* device_id, int64_t* row_offset) {
     int rc = check_index(ix);

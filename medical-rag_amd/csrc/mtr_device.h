@@ -81,6 +81,11 @@ hipError_t launch_merge_topk(const float* cand_s, const int* idx32, const long l
                              int b, int k_out, long long idx_offset, long long* out_idx,
                              float* out_score, hipStream_t stream);
 
+// Masked mean pooling over tokens + L2 normalisation of encoder outputs:
+// hidden [b][t][d] (dtype 0 fp32, 2 bf16, 3 fp16), mask [b][t] int64 -> out [b][d] fp32.
+hipError_t launch_pool_normalize(const void* hidden, int dtype, const long long* mask, int b, int t, int d, float* out,
+                                 hipStream_t stream);
+
 struct MfmaPlan {
     int cap;                  // candidate slots per (workgroup, query): 256 or 512
     int slack;                // extra keys an in-loop re-selection may keep

@@ -1,0 +1,105 @@
+"""Binary sidecar for the page-embedding index.
+
+The reference keeps the index as one JSON list of {"index", "text",
+"embedding": [d floats]} (written at pipeline/utils/embed.py:74-79,110-113,
+parsed whole by pipeline/utils/local_rag.py:90-101): 470 MB of text and ten
+seconds of json.load for 4032 x 4096, and no path to 10^6+ rows.  The sidecar
+stores the same rows as raw little-endian fp32 behind a fixed header, plus the
+page dicts (everything but the vectors) as JSON; the matrix is memory-mapped
+and streamed to the GPU in chunks.
+
+    <index>.json          the reference's file (source of truth)
+    <index>.json.mtr      header (64 bytes) + n*d float32, C order
+    <index>.json.pages    JSON list of the page dicts without "embedding"
+
+Header: magic "MTRIDX1\\0", u64 n, u32 d, u32 dtype (0 = fp32), u64 size and
+i64 mtime_ns of the JSON the sidecar was made from (0/0 when built without
+one), 24 bytes reserved.  A sidecar whose recorded size/mtime do not match its
+JSON is stale and ignored.
+"""
+from __future__ import annotations
+
+import json
+import os
+import struct
+
+import numpy as np
+
+MAGIC = b"MTRIDX1\0"
+HEADER = struct.Struct("<8sQIIQq24x")
+assert HEADER.size == 64
+
+
+def sidecar_paths(json_path: str):
+    return json_path + ".mtr", json_path + ".pages"
+
+
+def write_sidecar(json_path: str, matrix: np.ndarray, pages_meta: list, bind_to_source: bool = True):
+    """Writes <json_path>.mtr / .pages for an (n, d) matrix and its page dicts."""
+    matrix = np.ascontiguousarray(matrix, dtype=np.float32)
+    if matrix.ndim != 2 or len(pages_meta) != matrix.shape[0]:
+        raise ValueError("matrix must be (n, d) with one page dict per row")
+    size = mtime = 0
+    if bind_to_source and os.path.exists(json_path):
+        st = os.stat(json_path)
+        size, mtime = st.st_size, st.st_mtime_ns
+    mtr, pages = sidecar_paths(json_path)
+    tmp = mtr + ".tmp"
+    with open(tmp, "wb") as f:
+        f.write(HEADER.pack(MAGIC, matrix.shape[0], matrix.shape[1], 0, size, mtime))
+        matrix.tofile(f)
+    os.replace(tmp, mtr)
+    tmp = pages + ".tmp"
+    with open(tmp, "w", encoding="utf-8") as f:
+        json.dump(pages_meta, f)
+    os.replace(tmp, pages)
+    return mtr, pages
+
+
+def convert(json_path: str):
+    """Parses the reference's JSON index once and writes its sidecar."""
+    with open(json_path, "r", encoding="utf-8") as f:
+        pages = json.load(f)
+    if not pages:
+        raise ValueError("empty index")
+    matrix = np.array([p["embedding"] for p in pages], dtype=np.float32)
+    meta = [{k: v for k, v in p.items() if k != "embedding"} for p in pages]
+    return write_sidecar(json_path, matrix, meta)
+
+
+def read_header(mtr_path: str):
+    with open(mtr_path, "rb") as f:
+        raw = f.read(HEADER.size)
+    if len(raw) != HEADER.size:
+        raise ValueError("truncated sidecar header")
+    magic, n, d, dtype, size, mtime = HEADER.unpack(raw)
+    if magic != MAGIC:
+        raise ValueError("not an MTRIDX1 sidecar")
+    if dtype != 0:
+        raise ValueError(f"unsupported sidecar dtype {dtype}")
+    return {"n": n, "d": d, "dtype": dtype, "source_size": size, "source_mtime_ns": mtime}
+
+
+def open_sidecar(json_path: str):
+    """(memory-mapped (n, d) float32 matrix, page dicts) when a fresh sidecar
+    exists for json_path, else None."""
+    mtr, pages = sidecar_paths(json_path)
+    if not (os.path.exists(mtr) and os.path.exists(pages)):
+        return None
+    try:
+        hdr = read_header(mtr)
+    except (OSError, ValueError):
+        return None
+    if os.path.exists(json_path):
+        st = os.stat(json_path)
+        if (hdr["source_size"], hdr["source_mtime_ns"]) not in ((st.st_size, st.st_mtime_ns), (0, 0)):
+            return None  # the JSON changed after the sidecar was written
+    expect = HEADER.size + hdr["n"] * hdr["d"] * 4
+    if os.path.getsize(mtr) != expect:
+        return None
+    matrix = np.memmap(mtr, dtype="<f4", mode="r", offset=HEADER.size, shape=(hdr["n"], hdr["d"]))
+    with open(pages, "r", encoding="utf-8") as f:
+        meta = json.load(f)
+    if len(meta) != hdr["n"]:
+        return None
+    return matrix, meta

@@ -25,7 +25,7 @@ from pathlib import Path
 
 import numpy as np
 
-from . import _native
+from . import _native, index_format
 
 __all__ = ["PageIndex", "load_embeddings", "embed_queries", "retrieve_top_index", "get_surrounding_pages", "search",
            "configure"]
@@ -149,6 +149,12 @@ def load_embeddings(path: str):
     if not path_obj.exists():
         logging.error(f"Embedding file not found: {path_obj}")
         return []
+    cached = index_format.open_sidecar(str(path_obj))
+    if cached is not None:
+        matrix, meta = cached
+        index = PageIndex.from_matrix(matrix, meta)
+        logging.info(f"Loaded {len(index)} page embeddings (d={index.shard.d}) from the binary sidecar of {path_obj}")
+        return index
     try:
         with open(path_obj, "r", encoding="utf-8") as f:
             pages = json.load(f)
@@ -220,6 +226,9 @@ def pool_and_normalize(last_hidden_state, attention_mask):
     """Masked mean over tokens then L2 normalisation, the arithmetic of
     pipeline/utils/local_rag.py:58-65 (torch tensors in, (B, d) tensor out)."""
     import torch
+    if last_hidden_state.is_cuda:
+        # one fused HIP kernel instead of five elementwise/reduction launches
+        return _native.pool_normalize(last_hidden_state, attention_mask)
     mask = attention_mask.to(last_hidden_state.dtype).unsqueeze(-1)
     summed = (last_hidden_state * mask).sum(dim=1)
     counts = mask.sum(dim=1).clamp(min=1e-9)

@@ -375,3 +375,58 @@ def test_merge_reads_packed_gathered_buffer(native):
     check_topk(gi.cpu().numpy(), gs.cpu().numpy(), orc.scores(queries, corpus), k, 1e-6, exact_idx=True)
     for sh in shards:
         sh.close()
+
+
+def test_sidecar_load_matches_json_load(rag, tmp_path):
+    import json
+    from medical_rag_amd import index_format
+    rng = np.random.default_rng(41)
+    mat = rng.standard_normal((500, 96)).astype(np.float32)
+    pages = [{"index": i % 7, "text": f"p{i}", "embedding": r.tolist()} for i, r in enumerate(mat)]
+    path = tmp_path / "embedded_pages_hf_x.json"
+    path.write_text(json.dumps(pages))
+    queries = rng.standard_normal((6, 96)).astype(np.float32)
+    from_json = rag.load_embeddings(str(path))
+    want = from_json.search(queries, k=9)
+    index_format.convert(str(path))
+    from_sidecar = rag.load_embeddings(str(path))
+    got = from_sidecar.search(queries, k=9)
+    assert (got[0] == want[0]).all() and (got[1] == want[1]).all()
+    assert list(from_sidecar) == list(from_json)
+    assert rag.get_surrounding_pages(3, from_sidecar) == rag.get_surrounding_pages(3, from_json)
+
+
+def test_batched_caller_matches_reference_loop(rag, golden):
+    from medical_rag_amd import caller
+    a, e = golden("g6_caller_glue")
+    pages = [{"index": i % 1000, "text": f"page-{i}"} for i in range(a["corpus"].shape[0])]
+    index = rag.PageIndex.from_matrix(a["corpus"], pages)
+    cases = [{"case_id": c["case_id"], "original_keywords": c["keywords"]} for c in e["cases"]]
+    assert caller.unique_keywords(cases) == e["unique_keywords"]
+    kw_map = {}
+    for kw in e["unique_keywords"]:
+        v = np.random.default_rng(zlib.crc32(kw.encode("utf-8"))).standard_normal(e["d"]).astype(np.float32)
+        kw_map[kw] = v / np.float32(np.linalg.norm(v))
+    kw_map["never used"] = np.array([])          # empty vector: skipped, as at retrieval.py:74
+    got = caller.local_pages_for_cases(cases, kw_map, index)
+    want = [{kw: v["pages"] for kw, v in c["local_pages_per_keyword"].items()} for c in e["expected"]]
+    assert got == want
+
+
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16", "float16"])
+def test_pool_normalize_matches_torch(native, dtype):
+    import torch
+    torch.manual_seed(3)
+    for b, t, d in ((5, 17, 1024), (3, 40, 4096), (2, 9, 100), (1, 1, 7)):
+        h = torch.randn(b, t, d, device="cuda").to(getattr(torch, dtype))
+        mask = (torch.rand(b, t, device="cuda") > 0.3).long()
+        mask[:, 0] = 1
+        if b > 1:
+            mask[1] = 0                                  # an all-padding row: zero vector, no NaN
+        got = native.pool_normalize(h, mask)
+        hf = h.float()
+        m = mask.unsqueeze(-1).expand(hf.size()).float()  # the reference's expression, local_rag.py:61-65
+        want = torch.nn.functional.normalize((hf * m).sum(1) / torch.clamp(m.sum(1), min=1e-9), p=2, dim=1)
+        assert got.dtype == torch.float32 and got.shape == (b, d)
+        assert torch.isfinite(got).all()
+        torch.testing.assert_close(got, want, atol=2e-6, rtol=1e-5)
