@@ -229,5 +229,45 @@ def g6():
           "expected": expected})
 
 
+TINY_VOCAB = (["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"]
+              + "lung edema pleural effusion cardiac pneumonia normal heart chest left right lobe opacity mass "
+                "the of and with no is".split() + ["##s", "##ing", "##al"])
+G7_QUERIES = ["pleural effusion", "normal heart", "left lung mass with edema", "pneumonia", "cardiac", "unknownword"]
+G7_PAGES = [{"index": i % 3, "markdown": t} for i, t in enumerate([
+    "the left lung is normal", "pleural effusion with opacity of the right lobe", "", "cardiac mass",
+    "no pneumonia and no edema the heart is normal the chest is normal"])]
+
+
+def g7():
+    """Encoder side (a2, a6): a tiny random-weight BERT saved under
+    tests/golden/tiny_encoder (so no download is needed), embedded with the
+    reference's own embed_queries and generate_embeddings_hf."""
+    import io
+    import contextlib
+    import torch
+    from transformers import BertConfig, BertModel, BertTokenizer
+    tiny = os.path.join(HERE, "tiny_encoder")
+    if not os.path.exists(os.path.join(tiny, "model.safetensors")):
+        os.makedirs(tiny, exist_ok=True)
+        with open(os.path.join(tiny, "vocab.txt"), "w") as f:
+            f.write("\n".join(TINY_VOCAB) + "\n")
+        BertTokenizer(os.path.join(tiny, "vocab.txt")).save_pretrained(tiny)
+        torch.manual_seed(0)
+        cfg = BertConfig(vocab_size=len(TINY_VOCAB), hidden_size=32, num_hidden_layers=2, num_attention_heads=4,
+                         intermediate_size=64, max_position_embeddings=64)
+        BertModel(cfg).save_pretrained(tiny)
+    q_all = ref.embed_queries(G7_QUERIES, tiny, "cpu")
+    q_bs2 = ref.embed_queries(G7_QUERIES, tiny, "cpu", batch_size=2)
+    sys.path.insert(0, os.path.join(REF, "pipeline", "utils"))
+    import embed as ref_embed  # the reference's index builder
+    with contextlib.redirect_stdout(io.StringIO()):
+        pages = ref_embed.generate_embeddings_hf(G7_PAGES, tiny, "cpu", batch_size=2)
+    save("g7_encoder", {"queries_bs64": np.stack(q_all), "queries_bs2": np.stack(q_bs2),
+                        "page_vectors": np.array([p["embedding"] for p in pages], dtype=np.float64)},
+         {"queries": G7_QUERIES, "pages_in": G7_PAGES,
+          "pages_out": [{k: v for k, v in p.items() if k != "embedding"} for p in pages],
+          "model_dir": "tests/golden/tiny_encoder"})
+
+
 if __name__ == "__main__":
-    g1(); g2(); g3(); g4(); g5(); g6()
+    g1(); g2(); g3(); g4(); g5(); g6(); g7()

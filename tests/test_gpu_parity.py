@@ -430,3 +430,12 @@ def test_pool_normalize_matches_torch(native, dtype):
         assert got.dtype == torch.float32 and got.shape == (b, d)
         assert torch.isfinite(got).all()
         torch.testing.assert_close(got, want, atol=2e-6, rtol=1e-5)
+
+
+def test_embed_queries_on_gpu_matches_reference(rag, golden):
+    """Encoder forward in PyTorch-ROCm, pooling + normalisation in the HIP kernel."""
+    import os
+    a, e = golden("g7_encoder")
+    tiny = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tiny_encoder")
+    got = rag.embed_queries(e["queries"], tiny, "cuda", batch_size=4)
+    np.testing.assert_allclose(np.stack(got), a["queries_bs64"], atol=2e-5, rtol=0)
