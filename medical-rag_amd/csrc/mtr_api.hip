@@ -96,7 +96,7 @@ struct mtr_index {
     DevBuf q_f32;      // padded fp32 queries of one pass
     DevBuf q_in;       // staging for host queries
     DevBuf cand_s, cand_i;
-    DevBuf q_bf16;     // bf16 query tiles for the matrix-core kernel
+    DevBuf q_bf16;     // query tiles (storage type) for the matrix-core kernel
     DevBuf mfma_cand;  // its workgroups' candidate buffers
     DevBuf mfma_floor; // per-query floor shared by the row ranges
     DevBuf out_i, out_s;
@@ -122,12 +122,13 @@ int check_index(const mtr_index* ix) {
 // q_dtype on the shard's device.  check_flag: leave the loader's non-finite
 // flag set for the caller to read.
 // Smallest batch that goes to the matrix-core kernel (bf16 shards only); below
-// it the HBM-bound scan handles the batch in passes of up to 8 queries.
+// it the HBM-bound scan handles the batch (measured hand-over on 1M x 1024:
+// two queries 0.46 ms by the scan, four 0.80 ms by the scan vs 0.65 ms here).
 int mfma_min_batch() {
     static const int v = [] {
         const char* e = getenv("MTR_MFMA_MIN_BATCH");
         const int x = e ? atoi(e) : 0;
-        return x > 0 ? x : 17;
+        return x > 0 ? x : 3;
     }();
     return v;
 }
@@ -137,7 +138,7 @@ int mfma_min_batch() {
 int enqueue_mfma(mtr_index* ix, const mtr::MfmaPlan& plan, const void* dev_queries, int q_dtype, int b, int k,
                  int metric, long long* dev_out_idx, float* dev_out_score, hipStream_t stream) {
     int rc;
-    const size_t qbytes = (size_t)plan.n_qtiles * 128 * ix->ld * 2;
+    const size_t qbytes = (size_t)plan.n_qtiles * 128 * ix->ld * dtype_size(ix->dtype);
     if ((rc = ix->q_bf16.reserve(qbytes)) != MTR_OK) return rc;
     if ((rc = ix->mfma_cand.reserve(plan.cand_bytes)) != MTR_OK) return rc;
     if ((rc = ix->cand_s.reserve((size_t)b * plan.n_ranges * k * 4)) != MTR_OK) return rc;
@@ -146,7 +147,7 @@ int enqueue_mfma(mtr_index* ix, const mtr::MfmaPlan& plan, const void* dev_queri
     if ((rc = ix->mfma_floor.reserve(floor_bytes)) != MTR_OK) return rc;
     HIP_TRY(hipMemsetAsync(ix->mfma_floor.p, 0, floor_bytes, stream));
     HIP_TRY(hipMemsetAsync(ix->q_bf16.p, 0, qbytes, stream));
-    HIP_TRY(mtr::launch_load_rows(dev_queries, q_dtype, b, ix->d, ix->q_bf16.p, MTR_BF16, ix->ld,
+    HIP_TRY(mtr::launch_load_rows(dev_queries, q_dtype, b, ix->d, ix->q_bf16.p, ix->dtype, ix->ld,
                                   metric == MTR_COSINE ? 1 : 0, ix->flag, stream));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ix->profiling) {
@@ -161,7 +162,7 @@ int enqueue_mfma(mtr_index* ix, const mtr::MfmaPlan& plan, const void* dev_queri
         ix->events_used++;
         HIP_TRY(hipEventRecord(e0, stream));
     }
-    HIP_TRY(mtr::launch_score_mfma(ix->rows, ix->n, ix->ld, ix->q_bf16.p, b, k, plan, ix->mfma_cand.p,
+    HIP_TRY(mtr::launch_score_mfma(ix->rows, ix->dtype, ix->n, ix->ld, ix->q_bf16.p, b, k, plan, ix->mfma_cand.p,
                                    static_cast<unsigned int*>(ix->mfma_floor.p), static_cast<float*>(ix->cand_s.p), static_cast<int*>(ix->cand_i.p), stream));
     if (ix->profiling) HIP_TRY(hipEventRecord(e1, stream));
     HIP_TRY(mtr::launch_merge_topk(static_cast<const float*>(ix->cand_s.p), static_cast<const int*>(ix->cand_i.p),
@@ -174,9 +175,9 @@ int enqueue_search(mtr_index* ix, const void* dev_queries, int q_dtype, int b, i
                    long long* dev_out_idx, float* dev_out_score, hipStream_t stream) {
     if (metric == MTR_COSINE && !ix->normalized)
         return fail(MTR_ERR_INVALID, "cosine search needs a shard built with normalize=1");
-    if (ix->dtype == MTR_BF16 && b >= mfma_min_batch()) {
+    if (b >= mfma_min_batch()) {
         mtr::MfmaPlan mplan;
-        if (mtr::plan_mfma(ix->n, ix->ld, b, k, ix->num_cus, &mplan) == 0)
+        if (mtr::plan_mfma(ix->dtype, ix->n, ix->ld, b, k, ix->num_cus, &mplan) == 0)
             return enqueue_mfma(ix, mplan, dev_queries, q_dtype, b, k, metric, dev_out_idx, dev_out_score, stream);
     }
     mtr::ScanPlan plan;
@@ -189,12 +190,16 @@ int enqueue_search(mtr_index* ix, const void* dev_queries, int q_dtype, int b, i
     const int qsize = dtype_size(q_dtype);
     for (int b0 = 0; b0 < b; b0 += plan.qb) {
         const int nb = std::min(plan.qb, b - b0);
-        // Padded fp32 queries (the loader writes all qstride columns of each
-        // query it converts); unused query slots of a short pass are zeroed.
-        if (nb < plan.qb) HIP_TRY(hipMemsetAsync(ix->q_f32.p, 0, (size_t)plan.qb * plan.qstride * 4, stream));
-        HIP_TRY(mtr::launch_load_rows(static_cast<const char*>(dev_queries) + (size_t)b0 * ix->d * qsize, q_dtype, nb,
-                                      ix->d, ix->q_f32.p, MTR_F32, plan.qstride, metric == MTR_COSINE ? 1 : 0,
-                                      ix->flag, stream));
+        // fp32 queries are normalised and padded inside the scan kernel; other
+        // types go through the loader first (it writes all qstride columns of
+        // each query it converts; unused slots of a short pass are zeroed).
+        const char* qsrc = static_cast<const char*>(dev_queries) + (size_t)b0 * ix->d * qsize;
+        const bool raw = q_dtype == MTR_F32;
+        if (!raw) {
+            if (nb < plan.qb) HIP_TRY(hipMemsetAsync(ix->q_f32.p, 0, (size_t)plan.qb * plan.qstride * 4, stream));
+            HIP_TRY(mtr::launch_load_rows(qsrc, q_dtype, nb, ix->d, ix->q_f32.p, MTR_F32, plan.qstride,
+                                          metric == MTR_COSINE ? 1 : 0, ix->flag, stream));
+        }
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (ix->profiling) {
             if (ix->events_used == ix->events.size()) {
@@ -209,7 +214,8 @@ int enqueue_search(mtr_index* ix, const void* dev_queries, int q_dtype, int b, i
             HIP_TRY(hipEventRecord(e0, stream));
         }
         HIP_TRY(mtr::launch_scan_topk(ix->rows, ix->dtype, ix->n, ix->ld, ix->d, static_cast<const float*>(ix->q_f32.p),
-                                      k, plan, static_cast<float*>(ix->cand_s.p), static_cast<int*>(ix->cand_i.p),
+                                      raw ? reinterpret_cast<const float*>(qsrc) : nullptr, nb,
+                                      metric == MTR_COSINE ? 1 : 0, ix->flag, k, plan, static_cast<float*>(ix->cand_s.p), static_cast<int*>(ix->cand_i.p),
                                       stream));
         if (ix->profiling) HIP_TRY(hipEventRecord(e1, stream));
         HIP_TRY(mtr::launch_merge_topk(static_cast<const float*>(ix->cand_s.p), static_cast<const int*>(ix->cand_i.p),

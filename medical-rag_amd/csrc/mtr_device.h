@@ -67,9 +67,12 @@ int plan_scan(int dtype, int64_t n, int d, int ld, int b, int k, int num_cus, Sc
 // Row scan + fused per-workgroup top-k.  q: plan.qb padded fp32 queries
 // ([qb][qstride]); outputs [qb][grid][k] candidate (score, local row) lists,
 // each sorted, padded with (-inf, -1).
+// Instead of prepared queries (q), the first nb raw fp32 queries ([nb][d],
+// q_raw != NULL) can be given: every workgroup then normalises (if asked) and
+// pads them itself and reports NaN/inf through nonfinite_flag.
 hipError_t launch_scan_topk(const void* rows, int dtype, int64_t n, int ld, int d, const float* q,
-                            int k, const ScanPlan& plan, float* cand_s, int* cand_i,
-                            hipStream_t stream);
+                            const float* q_raw, int nb, int normalize, int* nonfinite_flag, int k,
+                            const ScanPlan& plan, float* cand_s, int* cand_i, hipStream_t stream);
 
 // Candidate merge: for each of b queries, the best k_out of n_lists * k_in
 // candidates.  Candidate (list l, query q, slot j) sits at
@@ -98,14 +101,15 @@ struct MfmaPlan {
 };
 
 // Launch shape of the matrix-core scoring kernel; -1 when the shape is not
-// covered (row stride not a multiple of 64 elements, or k > 256).
-int plan_mfma(int64_t n, int ld, int b, int k, int num_cus, MfmaPlan* plan);
+// covered (row stride not a multiple of 128 bytes or shorter than 256, or k > 256).
+int plan_mfma(int dtype, int64_t n, int ld, int b, int k, int num_cus, MfmaPlan* plan);
 
-// bf16 rows x bf16 queries on the matrix cores with fused top-k.  queries_bf16:
+// rows x queries on the matrix cores with fused top-k, both in the shard's storage type
+// (dtype 0 fp32: exact-fp32 MFMA; 2 bf16).  queries:
 // [n_qtiles*128][ld], rows past b zero.  shared_floor: n_qtiles*128 words, zeroed by the
 // caller before every launch.  Outputs [b][n_ranges][k] candidate
 // lists (unsorted, padded with (-inf, -1)).
-hipError_t launch_score_mfma(const void* rows, int64_t n, int ld, const void* queries_bf16, int b, int k,
+hipError_t launch_score_mfma(const void* rows, int dtype, int64_t n, int ld, const void* queries, int b, int k,
                              const MfmaPlan& plan, void* cand_buf, unsigned int* shared_floor, float* out_s,
                              int* out_i, hipStream_t stream);
 

@@ -75,7 +75,12 @@ struct ScanArgs {
     long long row_bytes;
     int nchunks;   // 16-byte chunks per row that hold data
     int nit;       // sweeps per row = ceil(nchunks / 64)
-    const float* q;
+    const float* q;       // prepared queries [QB][qstride] (used when q_raw is null)
+    const float* q_raw;   // or: nb raw fp32 queries [nb][d], normalised and padded by every workgroup itself
+    int d;
+    int nb;
+    int normalize;
+    int* nonfinite_flag;  // set when a raw query holds NaN/inf
     int qstride;   // floats per padded query = nit * 64 * EPC
     int k;
     float* cand_s; // [QB][gridDim.x][k]
@@ -100,7 +105,42 @@ __global__ __launch_bounds__(waves_per_group(QB) * 64) void scan_topk_kernel(Sca
     const int lane = tid & 63;
     const int wave = tid >> 6;
 
-    {
+    if (a.q_raw) {
+        // fp32 queries straight from the caller: float64 norm (zero norm counts as
+        // 1, as for the rows), scale, zero-pad -- redone by every workgroup, which
+        // is cheaper than a kernel boundary.
+        // One wave per query (waves take queries round-robin), so no workgroup
+        // barrier is needed until all queries are in place.
+        for (int b = wave; b < QB; b += kWaves) {
+            float* dst = q_lds + (size_t)b * a.qstride;
+            if (b >= a.nb) {
+                for (int e = lane; e < a.qstride; e += 64) dst[e] = 0.f;
+                continue;
+            }
+            const float* src = a.q_raw + (size_t)b * a.d;
+            double ss = 0.0;
+            bool bad = false;
+            for (int e = lane; e < a.d; e += 64) {
+                const double x = (double)src[e];
+                bad |= !(fabs(x) <= 1.7976931348623157e308);
+                ss += x * x;
+            }
+            if (__ballot(bad) != 0ull && lane == 0 && blockIdx.x == 0) atomicOr(a.nonfinite_flag, 1);
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                int lo = __double2loint(ss), hi = __double2hiint(ss);
+                lo = __shfl_xor(lo, m, 64);
+                hi = __shfl_xor(hi, m, 64);
+                ss += __hiloint2double(hi, lo);
+            }
+            double norm = 1.0;
+            if (a.normalize) {
+                norm = sqrt(ss);
+                if (!(norm >= 10.0 * 2.220446049250313e-16)) norm = 1.0;
+            }
+            for (int e = lane; e < a.qstride; e += 64) dst[e] = e < a.d ? (float)((double)src[e] / norm) : 0.f;
+        }
+    } else {
         const int n4 = QB * a.qstride / 4;
         const f32x4* src = reinterpret_cast<const f32x4*>(a.q);
         f32x4* dst = reinterpret_cast<f32x4*>(q_lds);
@@ -268,7 +308,8 @@ int plan_scan(int dtype, int64_t n, int d, int ld, int b, int k, int num_cus, Sc
     plan->nit = (nchunks + 63) / 64;
     plan->qstride = plan->nit * 64 * epc;
     int qb = 1;
-    while (qb < b && qb < 8) qb *= 2;
+    // Four queries per pass cost the least per query (measured); eight run out of registers.
+    while (qb < b && qb < 4) qb *= 2;
     constexpr size_t kLdsBudget = 150 * 1024;  // of the CU's 160 KiB
     while (qb > 1 && scan_lds_bytes(qb, plan->qstride, k) > kLdsBudget) qb /= 2;
     if (scan_lds_bytes(qb, plan->qstride, k) > kLdsBudget) return -1;
@@ -291,7 +332,8 @@ int plan_scan(int dtype, int64_t n, int d, int ld, int b, int k, int num_cus, Sc
     return 0;
 }
 
-hipError_t launch_scan_topk(const void* rows, int dtype, int64_t n, int ld, int d, const float* q, int k,
+hipError_t launch_scan_topk(const void* rows, int dtype, int64_t n, int ld, int d, const float* q,
+                            const float* q_raw, int nb, int normalize, int* nonfinite_flag, int k,
                             const ScanPlan& plan, float* cand_s, int* cand_i, hipStream_t stream) {
     const int esize = dtype == 0 ? 4 : 2;
     ScanArgs a;
@@ -301,6 +343,11 @@ hipError_t launch_scan_topk(const void* rows, int dtype, int64_t n, int ld, int 
     a.nchunks = (d * esize + 15) / 16;
     a.nit = plan.nit;
     a.q = q;
+    a.q_raw = q_raw;
+    a.d = d;
+    a.nb = nb;
+    a.normalize = normalize;
+    a.nonfinite_flag = nonfinite_flag;
     a.qstride = plan.qstride;
     a.k = k;
     a.cand_s = cand_s;

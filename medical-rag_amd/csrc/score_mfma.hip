@@ -47,20 +47,22 @@ namespace {
 
 constexpr int TM = 128;   // rows per tile
 constexpr int TN = 128;   // queries per tile
-constexpr int BK = 64;    // K elements per step
+constexpr int kStepBytes = 128;  // K bytes of a row per step: 64 bf16 or 32 fp32
 constexpr int kThreads = 256;
-constexpr int kStageBytes = (TM + TN) * BK * 2;  // 32 KiB: row tile then query tile
+constexpr int kStageBytes = (TM + TN) * kStepBytes;  // 32 KiB: row tile then query tile
 
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
+using f32x4v = __attribute__((ext_vector_type(4))) float;
+
 struct MfmaArgs {
-    const bf16_t* rows;      // [n][ld]
+    const char* rows;        // [n][ld] elements of T
     long long n;
-    int ld;                  // elements, multiple of BK
-    const bf16_t* queries;   // [n_qtiles*TN][ld], zero rows past b
+    int ld;                  // elements; ld * sizeof(T) is a multiple of kStepBytes
+    const char* queries;     // [n_qtiles*TN][ld] elements of T, zero rows past b
     int b;
     int n_qtiles;
     int n_ranges;
@@ -77,8 +79,8 @@ struct MfmaArgs {
 };
 
 template <int AUX>
-__device__ __forceinline__ void stage_tile(const bf16_t* base, long long row0, long long row_max, int ld, int k0,
-                                           char* lds, int wave, int lane) {
+__device__ __forceinline__ void stage_tile(const char* base, long long row0, long long row_max, long long row_bytes,
+                                           int k0_bytes, char* lds, int wave, int lane) {
     // 128 rows x 128 bytes.  One wave instruction fills 8 rows; lane L writes
     // LDS position (row L/8, slot L%8) and fetches chunk (L%8) ^ (L/8) of it.
 #pragma unroll
@@ -88,13 +90,79 @@ __device__ __forceinline__ void stage_tile(const bf16_t* base, long long row0, l
         long long row = row0 + r;
         row = row < row_max ? row : row_max;
         const int chunk = (lane & 7) ^ (lane >> 3);
-        const bf16_t* src = base + row * ld + k0 + chunk * 8;
+        const char* src = base + row * row_bytes + k0_bytes + chunk * 16;
         __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(lds + t * 1024), 16, 0, AUX);
     }
 }
 
 __device__ __forceinline__ bf16x8 read_frag(const char* lds, int row, int chunk) {
     return *reinterpret_cast<const bf16x8*>(lds + row * 128 + ((chunk ^ (row & 7)) << 4));
+}
+__device__ __forceinline__ f32x4v read_frag_f32(const char* lds, int row, int chunk) {
+    return *reinterpret_cast<const f32x4v*>(lds + row * 128 + ((chunk ^ (row & 7)) << 4));
+}
+
+// One K step (128 bytes of every row of the stage) of a wave's 64x64 sub-tile.
+// bf16: four v_mfma_f32_32x32x16_bf16 per 2x2 MFMA tile; lane half h supplies k
+// elements 8h..8h+7 of each 16-element block.
+// fp32: sixteen v_mfma_f32_32x32x2_f32 (exact fp32, an fmaf chain) per MFMA
+// tile.  Its K is 2 per instruction, lane half h supplying one of them; the
+// order of K inside a step is free as long as both operands agree, so half h
+// takes floats 16h..16h+15 of the step, which are four 16-byte reads.
+template <typename T>
+__device__ __forceinline__ void mfma_step(const char* sa, const char* sb, int wm, int wn, int lane,
+                                          f32x16 (&acc)[2][2]);
+
+template <>
+__device__ __forceinline__ void mfma_step<bf16_t>(const char* sa, const char* sb, int wm, int wn, int lane,
+                                                  f32x16 (&acc)[2][2]) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const int chunk = 2 * kk + (lane >> 5);
+        bf16x8 fa[2], fb[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) fa[m] = read_frag(sa, wm * 64 + m * 32 + (lane & 31), chunk);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) fb[n] = read_frag(sb, wn * 64 + n * 32 + (lane & 31), chunk);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m], fb[n], acc[m][n], 0, 0, 0);
+    }
+}
+
+template <>
+__device__ __forceinline__ void mfma_step<float>(const char* sa, const char* sb, int wm, int wn, int lane,
+                                                 f32x16 (&acc)[2][2]) {
+    // Each step's 32 products are summed in a fresh accumulator and then added
+    // to the running one: an fp32 MFMA is a plain fmaf chain, and one chain over
+    // all of d (4096 terms) drifts past 1e-6 for near-duplicate vectors; blocks
+    // of 32 keep the error near 1e-7.
+    f32x4v fb[2][4];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) fb[n][c] = read_frag_f32(sb, wn * 64 + n * 32 + (lane & 31), 4 * (lane >> 5) + c);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        f32x4v fa[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) fa[c] = read_frag_f32(sa, wm * 64 + m * 32 + (lane & 31), 4 * (lane >> 5) + c);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            f32x16 part;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part[r] = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    part = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][j], fb[n][c][j], part, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] += part[r];
+        }
+    }
 }
 
 // Re-selection of one query's buffer.
@@ -149,8 +217,10 @@ __device__ __forceinline__ void compact_query(unsigned long long* buf, int c, in
     finish_select<E>(buf, key, k, slack, floor_lds, cnt_lds, q, lane, shared_floor_q, hist);
 }
 
-template <int CAP, int ROW_AUX>
+template <typename T, int CAP>
 __global__ __launch_bounds__(kThreads, 2) void score_topk_mfma_kernel(MfmaArgs a) {
+    constexpr int ROW_AUX = 0;  // default cache policy for the row tiles (non-temporal measured 13-28 % slower)
+    constexpr int BK = kStepBytes / (int)sizeof(T);
     constexpr int E = CAP / 64;
     static_assert((CAP & (CAP - 1)) == 0, "CAP must be a power of two");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -180,6 +250,7 @@ __global__ __launch_bounds__(kThreads, 2) void score_topk_mfma_kernel(MfmaArgs a
     if (tile_hi > n_tiles) tile_hi = n_tiles;
     const long long my_tiles = tile_hi > tile_lo ? tile_hi - tile_lo : 0;
     const int ksteps = a.ld / BK;
+    const long long row_bytes = (long long)a.ld * (long long)sizeof(T);
 
     for (int i = tid; i < TN; i += kThreads) {
         const int qg = qt * TN + i;
@@ -192,7 +263,7 @@ __global__ __launch_bounds__(kThreads, 2) void score_topk_mfma_kernel(MfmaArgs a
     unsigned int* shared_floor = a.shared_floor + (size_t)qt * TN;
     unsigned int pending_floor = 0;  // threads < TN: the shared floor word fetched at the start of a tile
     unsigned long long* my_buf = a.cand_buf + (size_t)blockIdx.x * TN * CAP;
-    const bf16_t* qbase = a.queries + (size_t)qt * TN * a.ld;
+    const char* qbase = a.queries + (size_t)qt * TN * row_bytes;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -204,8 +275,8 @@ __global__ __launch_bounds__(kThreads, 2) void score_topk_mfma_kernel(MfmaArgs a
 
     const long long total_steps = my_tiles * ksteps;
     if (total_steps > 0) {
-        stage_tile<ROW_AUX>(a.rows, tile_lo * TM, a.n - 1, a.ld, 0, stage0, wave, lane);
-        stage_tile<0>(qbase, 0, TN - 1, a.ld, 0, stage0 + TM * BK * 2, wave, lane);
+        stage_tile<ROW_AUX>(a.rows, tile_lo * TM, a.n - 1, row_bytes, 0, stage0, wave, lane);
+        stage_tile<0>(qbase, 0, TN - 1, row_bytes, 0, stage0 + TM * kStepBytes, wave, lane);
     }
     __syncthreads();
 
@@ -218,25 +289,10 @@ __global__ __launch_bounds__(kThreads, 2) void score_topk_mfma_kernel(MfmaArgs a
         if (s + 1 < total_steps) {
             const int nks = ks + 1 == ksteps ? 0 : ks + 1;
             const long long ntile = ks + 1 == ksteps ? tile + 1 : tile;
-            stage_tile<ROW_AUX>(a.rows, ntile * TM, a.n - 1, a.ld, nks * BK, stage0 + (cur ^ 1) * kStageBytes, wave, lane);
-            stage_tile<0>(qbase, 0, TN - 1, a.ld, nks * BK, stage0 + (cur ^ 1) * kStageBytes + TM * BK * 2, wave, lane);
+            stage_tile<ROW_AUX>(a.rows, ntile * TM, a.n - 1, row_bytes, nks * kStepBytes, stage0 + (cur ^ 1) * kStageBytes, wave, lane);
+            stage_tile<0>(qbase, 0, TN - 1, row_bytes, nks * kStepBytes, stage0 + (cur ^ 1) * kStageBytes + TM * kStepBytes, wave, lane);
         }
-        const char* sa = stage0 + cur * kStageBytes;
-        const char* sb = stage0 + cur * kStageBytes + TM * BK * 2;
-#pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk) {
-            const int chunk = 2 * kk + (lane >> 5);
-            bf16x8 fa[2], fb[2];
-#pragma unroll
-            for (int m = 0; m < 2; ++m) fa[m] = read_frag(sa, wm * 64 + m * 32 + (lane & 31), chunk);
-#pragma unroll
-            for (int n = 0; n < 2; ++n) fb[n] = read_frag(sb, wn * 64 + n * 32 + (lane & 31), chunk);
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int n = 0; n < 2; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m], fb[n], acc[m][n], 0, 0, 0);
-        }
+        mfma_step<T>(stage0 + cur * kStageBytes, stage0 + cur * kStageBytes + TM * kStepBytes, wm, wn, lane, acc);
 
         const bool tile_done = ks + 1 == ksteps;
         if (tile_done) {
@@ -353,8 +409,9 @@ __global__ __launch_bounds__(kThreads, 2) void score_topk_mfma_kernel(MfmaArgs a
 
 }  // namespace
 
-int plan_mfma(int64_t n, int ld, int b, int k, int num_cus, MfmaPlan* plan) {
-    if (ld % BK != 0 || k < 1 || k > 256 || b < 1 || n < 1) return -1;
+int plan_mfma(int dtype, int64_t n, int ld, int b, int k, int num_cus, MfmaPlan* plan) {
+    const int esize = dtype == 0 ? 4 : 2;
+    if ((ld * esize) % kStepBytes != 0 || ld * esize < 2 * kStepBytes || k < 1 || k > 256 || b < 1 || n < 1) return -1;
     plan->cap = k <= 32 ? 256 : 512;
     if (const char* e = getenv("MTR_MFMA_CAP")) {
         const int c = atoi(e);
@@ -375,14 +432,14 @@ int plan_mfma(int64_t n, int ld, int b, int k, int num_cus, MfmaPlan* plan) {
     return 0;
 }
 
-hipError_t launch_score_mfma(const void* rows, int64_t n, int ld, const void* queries_bf16, int b, int k,
+hipError_t launch_score_mfma(const void* rows, int dtype, int64_t n, int ld, const void* queries, int b, int k,
                              const MfmaPlan& plan, void* cand_buf, unsigned int* shared_floor, float* out_s,
                              int* out_i, hipStream_t stream) {
     MfmaArgs a;
-    a.rows = static_cast<const bf16_t*>(rows);
+    a.rows = static_cast<const char*>(rows);
     a.n = n;
     a.ld = ld;
-    a.queries = static_cast<const bf16_t*>(queries_bf16);
+    a.queries = static_cast<const char*>(queries);
     a.b = b;
     a.n_qtiles = plan.n_qtiles;
     a.n_ranges = plan.n_ranges;
@@ -405,13 +462,6 @@ hipError_t launch_score_mfma(const void* rows, int64_t n, int ld, const void* qu
     a.shared_floor = shared_floor;
     a.out_s = out_s;
     a.out_i = out_i;
-    // Cache policy of the row-tile loads: default (0).  The non-temporal policy
-    // (aux 2, MTR_MFMA_ROW_AUX=2) measured 13-28 % slower here: every row tile
-    // is re-read through L2 by the workgroups of the other query tiles.
-    static const int row_aux = [] {
-        const char* e = getenv("MTR_MFMA_ROW_AUX");
-        return e ? atoi(e) : 0;
-    }();
     auto launch = [&](auto kernel) -> hipError_t {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds);
@@ -419,8 +469,9 @@ hipError_t launch_score_mfma(const void* rows, int64_t n, int ld, const void* qu
         hipLaunchKernelGGL(kernel, dim3(plan.grid), dim3(kThreads), plan.lds, stream, a);
         return hipGetLastError();
     };
-    if (plan.cap == 256) return row_aux == 2 ? launch(&score_topk_mfma_kernel<256, 2>) : launch(&score_topk_mfma_kernel<256, 0>);
-    return row_aux == 2 ? launch(&score_topk_mfma_kernel<512, 2>) : launch(&score_topk_mfma_kernel<512, 0>);
+    if (dtype == 0)
+        return plan.cap == 256 ? launch(&score_topk_mfma_kernel<float, 256>) : launch(&score_topk_mfma_kernel<float, 512>);
+    return plan.cap == 256 ? launch(&score_topk_mfma_kernel<bf16_t, 256>) : launch(&score_topk_mfma_kernel<bf16_t, 512>);
 }
 
 }  // namespace mtr
