@@ -41,7 +41,7 @@ WORKLOADS = {
     "c5shard": dict(rows=12_500_000, dim=768, store="bf16", batch=64, k=10,
                     name="one of the 8 shards of the 100Mx768 bf16 corpus (12.5M rows), 64-query batch, top-10"),
 }
-MFMA_PEAK_TFLOPS = 2500.0  # MI355X dense bf16 matrix peak
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # MI355X dense matrix peaks (fp32 = v_mfma_f32_32x32x2_f32)
 
 
 def needle_vector(torch, queries, qi, j, k, row, device):
@@ -228,17 +228,24 @@ def main():
         passes = n_launch / args.steps
         default_shape = world == 1 and not (args.rows or args.batch or args.k)
         traffic = pmc_traffic(args.workload, default_shape)
-        if batch >= 3 and store == "bf16":  # the matrix-core kernel served this batch
-            flops = 2.0 * batch * (hi - lo) * dim
+        # The library hands batches of >= 3 queries to the matrix-core kernel when
+        # rows are a multiple of 128 bytes (>= 256) and k <= 256.
+        min_b = int(os.environ.get("MTR_MFMA_MIN_BATCH", "3") or 3)
+        on_mfma = batch >= min_b and k <= 256 and (dim * esize) % 128 == 0 and dim * esize >= 256
+        kernel = "score_topk_mfma_kernel" if on_mfma else "scan_topk_kernel"
+        flops = 2.0 * batch * (hi - lo) * dim
+        peak_tf = MFMA_PEAK_TFLOPS[store]
+        # the roofline that binds is the one whose minimum time is longer
+        if on_mfma and flops / (peak_tf * 1e12) > local_bytes / (HBM_PEAK_GBS * 1e9):
             tf = flops / (scan_avg_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": tf / MFMA_PEAK_TFLOPS, "traffic": traffic, "kernel": "score_topk_mfma_kernel",
+            roof = {"bound": "mfma", "achieved": tf, "peak": peak_tf, "unit": "TFLOP/s",
+                    "frac": tf / peak_tf, "traffic": traffic, "kernel": kernel,
                     "kernel_avg_ms": scan_avg_ms, "launches_per_step": passes,
                     "algorithmic_flops_per_launch": flops}
         else:
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                    "kernel": "scan_topk_kernel", "kernel_avg_ms": scan_avg_ms,
+                    "kernel": kernel, "kernel_avg_ms": scan_avg_ms,
                     "launches_per_step": passes, "algorithmic_bytes_per_launch": local_bytes}
         res = {
             "metric": METRIC,

@@ -121,16 +121,18 @@ int check_index(const mtr_index* ix) {
 // Scoring + merge of one batch, enqueued on `stream`.  dev_queries: b x d in
 // q_dtype on the shard's device.  check_flag: leave the loader's non-finite
 // flag set for the caller to read.
-// Smallest batch that goes to the matrix-core kernel (bf16 shards only); below
-// it the HBM-bound scan handles the batch (measured hand-over on 1M x 1024:
-// two queries 0.46 ms by the scan, four 0.80 ms by the scan vs 0.65 ms here).
-int mfma_min_batch() {
-    static const int v = [] {
+// Smallest batch that goes to the matrix-core kernel; below it the HBM-bound
+// scan handles the batch in passes of up to four queries.  Measured hand-over
+// (1M rows): bf16 x 1024 -- scan 0.46 ms for two queries, 0.80 ms for four,
+// matrix cores (32-query tiles) 0.43 ms for three; fp32 x 768 -- scan 0.52 ms
+// for two, 0.80 ms for four, matrix cores (fp32 MFMA) 0.65 ms for three or four.
+int mfma_min_batch(int dtype) {
+    static const int forced = [] {
         const char* e = getenv("MTR_MFMA_MIN_BATCH");
-        const int x = e ? atoi(e) : 0;
-        return x > 0 ? x : 3;
+        return e ? atoi(e) : 0;
     }();
-    return v;
+    if (forced > 0) return forced;
+    return 3;
 }
 
 // Matrix-core path: bf16 queries, one fused score + top-k launch, then the
@@ -138,12 +140,12 @@ int mfma_min_batch() {
 int enqueue_mfma(mtr_index* ix, const mtr::MfmaPlan& plan, const void* dev_queries, int q_dtype, int b, int k,
                  int metric, long long* dev_out_idx, float* dev_out_score, hipStream_t stream) {
     int rc;
-    const size_t qbytes = (size_t)plan.n_qtiles * 128 * ix->ld * dtype_size(ix->dtype);
+    const size_t qbytes = (size_t)plan.n_qtiles * plan.tnq * ix->ld * dtype_size(ix->dtype);
     if ((rc = ix->q_bf16.reserve(qbytes)) != MTR_OK) return rc;
     if ((rc = ix->mfma_cand.reserve(plan.cand_bytes)) != MTR_OK) return rc;
     if ((rc = ix->cand_s.reserve((size_t)b * plan.n_ranges * k * 4)) != MTR_OK) return rc;
     if ((rc = ix->cand_i.reserve((size_t)b * plan.n_ranges * k * 4)) != MTR_OK) return rc;
-    const size_t floor_bytes = (size_t)plan.n_qtiles * 128 * 4;
+    const size_t floor_bytes = (size_t)plan.n_qtiles * plan.tnq * 4;
     if ((rc = ix->mfma_floor.reserve(floor_bytes)) != MTR_OK) return rc;
     HIP_TRY(hipMemsetAsync(ix->mfma_floor.p, 0, floor_bytes, stream));
     HIP_TRY(hipMemsetAsync(ix->q_bf16.p, 0, qbytes, stream));
@@ -175,7 +177,7 @@ int enqueue_search(mtr_index* ix, const void* dev_queries, int q_dtype, int b, i
                    long long* dev_out_idx, float* dev_out_score, hipStream_t stream) {
     if (metric == MTR_COSINE && !ix->normalized)
         return fail(MTR_ERR_INVALID, "cosine search needs a shard built with normalize=1");
-    if (b >= mfma_min_batch()) {
+    if (b >= mfma_min_batch(ix->dtype)) {
         mtr::MfmaPlan mplan;
         if (mtr::plan_mfma(ix->dtype, ix->n, ix->ld, b, k, ix->num_cus, &mplan) == 0)
             return enqueue_mfma(ix, mplan, dev_queries, q_dtype, b, k, metric, dev_out_idx, dev_out_score, stream);

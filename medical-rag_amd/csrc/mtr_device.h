@@ -92,7 +92,8 @@ hipError_t launch_pool_normalize(const void* hidden, int dtype, const long long*
 struct MfmaPlan {
     int cap;                  // candidate slots per (workgroup, query): 256 or 512
     int slack;                // extra keys an in-loop re-selection may keep
-    int n_qtiles;             // query tiles of 128
+    int tnq;                  // queries per tile: 32, 64 or 128 by batch size
+    int n_qtiles;             // query tiles
     int n_ranges;             // row ranges (= candidate lists per query)
     long long tiles_per_range;
     int grid;
@@ -106,7 +107,7 @@ int plan_mfma(int dtype, int64_t n, int ld, int b, int k, int num_cus, MfmaPlan*
 
 // rows x queries on the matrix cores with fused top-k, both in the shard's storage type
 // (dtype 0 fp32: exact-fp32 MFMA; 2 bf16).  queries:
-// [n_qtiles*128][ld], rows past b zero.  shared_floor: n_qtiles*128 words, zeroed by the
+// [n_qtiles*tnq][ld], rows past b zero.  shared_floor: n_qtiles*tnq words, zeroed by the
 // caller before every launch.  Outputs [b][n_ranges][k] candidate
 // lists (unsorted, padded with (-inf, -1)).
 hipError_t launch_score_mfma(const void* rows, int dtype, int64_t n, int ld, const void* queries, int b, int k,

@@ -46,10 +46,12 @@ namespace mtr {
 namespace {
 
 constexpr int TM = 128;   // rows per tile
-constexpr int TN = 128;   // queries per tile
+// Queries per tile are a template parameter TNQ, so that small batches do not
+// pay for 128 columns: 128 (waves 2x2, each 64 rows x 64 queries = 2x2 MFMA
+// tiles), 64 (waves 2x2, each 64 x 32 = 2x1) or 32 (waves 4x1, each 32 x 32).
 constexpr int kStepBytes = 128;  // K bytes of a row per step: 64 bf16 or 32 fp32
 constexpr int kThreads = 256;
-constexpr int kStageBytes = (TM + TN) * kStepBytes;  // 32 KiB: row tile then query tile
+constexpr int stage_bytes(int tnq) { return (TM + tnq) * kStepBytes; }  // row tile then query tile
 
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -78,14 +80,14 @@ struct MfmaArgs {
     int* out_i;
 };
 
-template <int AUX>
+template <int AUX, int ROWS>
 __device__ __forceinline__ void stage_tile(const char* base, long long row0, long long row_max, long long row_bytes,
                                            int k0_bytes, char* lds, int wave, int lane) {
-    // 128 rows x 128 bytes.  One wave instruction fills 8 rows; lane L writes
+    // ROWS rows x 128 bytes.  One wave instruction fills 8 rows; lane L writes
     // LDS position (row L/8, slot L%8) and fetches chunk (L%8) ^ (L/8) of it.
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int t = wave * 4 + i;
+    for (int i = 0; i < ROWS / 32; ++i) {
+        const int t = wave * (ROWS / 32) + i;
         const int r = t * 8 + (lane >> 3);
         long long row = row0 + r;
         row = row < row_max ? row : row_max;
@@ -109,48 +111,46 @@ __device__ __forceinline__ f32x4v read_frag_f32(const char* lds, int row, int ch
 // tile.  Its K is 2 per instruction, lane half h supplying one of them; the
 // order of K inside a step is free as long as both operands agree, so half h
 // takes floats 16h..16h+15 of the step, which are four 16-byte reads.
-template <typename T>
-__device__ __forceinline__ void mfma_step(const char* sa, const char* sb, int wm, int wn, int lane,
-                                          f32x16 (&acc)[2][2]);
-
-template <>
-__device__ __forceinline__ void mfma_step<bf16_t>(const char* sa, const char* sb, int wm, int wn, int lane,
-                                                  f32x16 (&acc)[2][2]) {
+// row_off / q_off: first row / query of the wave's sub-tile inside the tile;
+// MT x NT MFMA tiles of 32x32 per wave.
+template <int MT, int NT>
+__device__ __forceinline__ void mfma_step(bf16_t, const char* sa, const char* sb, int row_off, int q_off, int lane,
+                                          f32x16 (&acc)[MT][NT]) {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
         const int chunk = 2 * kk + (lane >> 5);
-        bf16x8 fa[2], fb[2];
+        bf16x8 fa[MT], fb[NT];
 #pragma unroll
-        for (int m = 0; m < 2; ++m) fa[m] = read_frag(sa, wm * 64 + m * 32 + (lane & 31), chunk);
+        for (int m = 0; m < MT; ++m) fa[m] = read_frag(sa, row_off + m * 32 + (lane & 31), chunk);
 #pragma unroll
-        for (int n = 0; n < 2; ++n) fb[n] = read_frag(sb, wn * 64 + n * 32 + (lane & 31), chunk);
+        for (int n = 0; n < NT; ++n) fb[n] = read_frag(sb, q_off + n * 32 + (lane & 31), chunk);
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int n = 0; n < 2; ++n)
+            for (int n = 0; n < NT; ++n)
                 acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m], fb[n], acc[m][n], 0, 0, 0);
     }
 }
 
-template <>
-__device__ __forceinline__ void mfma_step<float>(const char* sa, const char* sb, int wm, int wn, int lane,
-                                                 f32x16 (&acc)[2][2]) {
+template <int MT, int NT>
+__device__ __forceinline__ void mfma_step(float, const char* sa, const char* sb, int row_off, int q_off, int lane,
+                                          f32x16 (&acc)[MT][NT]) {
     // Each step's 32 products are summed in a fresh accumulator and then added
     // to the running one: an fp32 MFMA is a plain fmaf chain, and one chain over
     // all of d (4096 terms) drifts past 1e-6 for near-duplicate vectors; blocks
     // of 32 keep the error near 1e-7.
-    f32x4v fb[2][4];
+    f32x4v fb[NT][4];
 #pragma unroll
-    for (int n = 0; n < 2; ++n)
+    for (int n = 0; n < NT; ++n)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) fb[n][c] = read_frag_f32(sb, wn * 64 + n * 32 + (lane & 31), 4 * (lane >> 5) + c);
+        for (int c = 0; c < 4; ++c) fb[n][c] = read_frag_f32(sb, q_off + n * 32 + (lane & 31), 4 * (lane >> 5) + c);
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
+    for (int m = 0; m < MT; ++m) {
         f32x4v fa[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) fa[c] = read_frag_f32(sa, wm * 64 + m * 32 + (lane & 31), 4 * (lane >> 5) + c);
+        for (int c = 0; c < 4; ++c) fa[c] = read_frag_f32(sa, row_off + m * 32 + (lane & 31), 4 * (lane >> 5) + c);
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
+        for (int n = 0; n < NT; ++n) {
             f32x16 part;
 #pragma unroll
             for (int r = 0; r < 16; ++r) part[r] = 0.f;
@@ -217,8 +217,13 @@ __device__ __forceinline__ void compact_query(unsigned long long* buf, int c, in
     finish_select<E>(buf, key, k, slack, floor_lds, cnt_lds, q, lane, shared_floor_q, hist);
 }
 
-template <typename T, int CAP>
+template <typename T, int CAP, int TNQ>
 __global__ __launch_bounds__(kThreads, 2) void score_topk_mfma_kernel(MfmaArgs a) {
+    constexpr int TN = TNQ;
+    constexpr int MT = TNQ == 32 ? 1 : 2;        // MFMA tiles per wave along the rows
+    constexpr int NT = TNQ == 128 ? 2 : 1;       // ... and along the queries
+    constexpr int QPW = TNQ / 4;                 // queries each wave looks after
+    constexpr int kStageBytes = stage_bytes(TNQ);
     constexpr int ROW_AUX = 0;  // default cache policy for the row tiles (non-temporal measured 13-28 % slower)
     constexpr int BK = kStepBytes / (int)sizeof(T);
     constexpr int E = CAP / 64;
@@ -233,8 +238,8 @@ __global__ __launch_bounds__(kThreads, 2) void score_topk_mfma_kernel(MfmaArgs a
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave >> 1;  // which 64 rows of the tile
-    const int wn = wave & 1;   // which 64 queries of the tile
+    const int row_off = TNQ == 32 ? wave * 32 : (wave >> 1) * 64;   // the wave's rows inside the tile
+    const int q_off = TNQ == 32 ? 0 : (wave & 1) * (TNQ / 2);       // ... and its queries
 
     // XCD-aware, bijective workgroup remap: ids that land on one XCD become consecutive.
     const int nwg = gridDim.x;
@@ -265,18 +270,18 @@ __global__ __launch_bounds__(kThreads, 2) void score_topk_mfma_kernel(MfmaArgs a
     unsigned long long* my_buf = a.cand_buf + (size_t)blockIdx.x * TN * CAP;
     const char* qbase = a.queries + (size_t)qt * TN * row_bytes;
 
-    f32x16 acc[2][2];
+    f32x16 acc[MT][NT];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+        for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
     const long long total_steps = my_tiles * ksteps;
     if (total_steps > 0) {
-        stage_tile<ROW_AUX>(a.rows, tile_lo * TM, a.n - 1, row_bytes, 0, stage0, wave, lane);
-        stage_tile<0>(qbase, 0, TN - 1, row_bytes, 0, stage0 + TM * kStepBytes, wave, lane);
+        stage_tile<ROW_AUX, TM>(a.rows, tile_lo * TM, a.n - 1, row_bytes, 0, stage0, wave, lane);
+        stage_tile<0, TNQ>(qbase, 0, TN - 1, row_bytes, 0, stage0 + TM * kStepBytes, wave, lane);
     }
     __syncthreads();
 
@@ -289,24 +294,25 @@ __global__ __launch_bounds__(kThreads, 2) void score_topk_mfma_kernel(MfmaArgs a
         if (s + 1 < total_steps) {
             const int nks = ks + 1 == ksteps ? 0 : ks + 1;
             const long long ntile = ks + 1 == ksteps ? tile + 1 : tile;
-            stage_tile<ROW_AUX>(a.rows, ntile * TM, a.n - 1, row_bytes, nks * kStepBytes, stage0 + (cur ^ 1) * kStageBytes, wave, lane);
-            stage_tile<0>(qbase, 0, TN - 1, row_bytes, nks * kStepBytes, stage0 + (cur ^ 1) * kStageBytes + TM * kStepBytes, wave, lane);
+            stage_tile<ROW_AUX, TM>(a.rows, ntile * TM, a.n - 1, row_bytes, nks * kStepBytes, stage0 + (cur ^ 1) * kStageBytes, wave, lane);
+            stage_tile<0, TNQ>(qbase, 0, TN - 1, row_bytes, nks * kStepBytes, stage0 + (cur ^ 1) * kStageBytes + TM * kStepBytes, wave, lane);
         }
-        mfma_step<T>(stage0 + cur * kStageBytes, stage0 + cur * kStageBytes + TM * kStepBytes, wm, wn, lane, acc);
+        mfma_step<MT, NT>(T{}, stage0 + cur * kStageBytes, stage0 + cur * kStageBytes + TM * kStepBytes, row_off, q_off,
+                          lane, acc);
 
         const bool tile_done = ks + 1 == ksteps;
         if (tile_done) {
-            // Scores of 128 rows x 128 queries are complete: append what clears each query's floor.
-            const long long row_base = tile * TM + wm * 64 + 4 * (lane >> 5);
+            // Scores of the 128-row x TNQ-query tile are complete: append what clears each query's floor.
+            const long long row_base = tile * TM + row_off + 4 * (lane >> 5);
             const bool last_tile = (tile + 1) * TM > a.n;
 #pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                const int ql = wn * 64 + n * 32 + (lane & 31);
+            for (int n = 0; n < NT; ++n) {
+                const int ql = q_off + n * 32 + (lane & 31);
                 // "v > own floor && v >= shared floor" as ONE strict threshold: v >= sh is
                 // v > (largest float below sh); a NaN from sh = -inf loses the fmaxf.
                 const float thr = fmaxf(floor_lds[ql], unorder_f32(order_f32(shared_lds[ql]) - 1u));
 #pragma unroll
-                for (int m = 0; m < 2; ++m) {
+                for (int m = 0; m < MT; ++m) {
                     float mx = acc[m][n][0];
 #pragma unroll
                     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[m][n][r]);
@@ -354,17 +360,17 @@ __global__ __launch_bounds__(kThreads, 2) void score_topk_mfma_kernel(MfmaArgs a
         }
         __syncthreads();
         if (tile_done) {
-            // Wave w looks after queries [32w, 32w+32): re-select any whose buffer
+            // Wave w looks after queries [QPW*w, QPW*(w+1)): re-select any whose buffer
             // could overflow on the next tile (a tile adds at most TM entries).
             if (tid < TN) shared_lds[tid] = unorder_f32(pending_floor | (pending_floor == 0 ? 0x007fffffu : 0u));
-            const int c = cnt_lds[wave * 32 + (lane & 31)];
-            unsigned long long need = __ballot(lane < 32 && c + TM > CAP);  // k + slack + TM <= CAP by plan
+            const int c = cnt_lds[wave * QPW + (lane % QPW)];
+            unsigned long long need = __ballot(lane < QPW && c + TM > CAP);  // k + slack + TM <= CAP by plan
             if (a.debug_no_candidates & 2) need = 0;
             if ((a.debug_no_candidates & 4) && lane == 0 && need) atomicAdd(a.debug_counters + 1, (unsigned long long)__popcll(need));
             while (need) {
                 const int j = __ffsll((long long)need) - 1;
                 need &= need - 1;
-                const int q = wave * 32 + j;
+                const int q = wave * QPW + j;
                 const int cq = __builtin_amdgcn_readfirstlane(cnt_lds[q]);
                 compact_query<E>(my_buf + (size_t)q * CAP, cq, a.k, a.slack, floor_lds, cnt_lds, q, lane,
                                  shared_floor + q, hist_lds);
@@ -379,8 +385,8 @@ __global__ __launch_bounds__(kThreads, 2) void score_topk_mfma_kernel(MfmaArgs a
 
     // Final selection per query and one candidate list per (query, range).
     __syncthreads();
-    for (int j = 0; j < 32; ++j) {
-        const int q = wave * 32 + j;
+    for (int j = 0; j < QPW; ++j) {
+        const int q = wave * QPW + j;
         const int qg = qt * TN + q;
         if (qg >= a.b) continue;  // wave-uniform
         int cq = __builtin_amdgcn_readfirstlane(cnt_lds[q]);
@@ -419,16 +425,25 @@ int plan_mfma(int dtype, int64_t n, int ld, int b, int k, int num_cus, MfmaPlan*
     }
     plan->slack = (plan->cap - 128 - k) / 4;
     if (plan->slack > 64) plan->slack = 64;
-    plan->n_qtiles = (b + TN - 1) / TN;
+    plan->tnq = b <= 32 ? 32 : b <= 64 ? 64 : 128;
+    if (const char* e = getenv("MTR_MFMA_TNQ")) {
+        const int t = atoi(e);
+        if (t == 32 || t == 64 || t == 128) plan->tnq = t;
+    }
+    plan->n_qtiles = (b + plan->tnq - 1) / plan->tnq;
     const long long n_tiles = (n + TM - 1) / TM;
-    long long ranges = (2LL * num_cus + plan->n_qtiles - 1) / plan->n_qtiles;
+    // Two workgroups per CU measured best for every tile width: more, shorter
+    // row ranges cost more in top-k selection than they gain in bytes in flight.
+    long long per_cu = 2;
+    if (const char* e = getenv("MTR_MFMA_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
+    long long ranges = (per_cu * num_cus + plan->n_qtiles - 1) / plan->n_qtiles;
     if (ranges > n_tiles) ranges = n_tiles;
     if (ranges < 1) ranges = 1;
     plan->tiles_per_range = (n_tiles + ranges - 1) / ranges;
     plan->n_ranges = (int)((n_tiles + plan->tiles_per_range - 1) / plan->tiles_per_range);
     plan->grid = plan->n_qtiles * plan->n_ranges;
-    plan->lds = 2 * kStageBytes + TN * 12 + (kThreads / 64) * 1024;
-    plan->cand_bytes = (size_t)plan->grid * TN * plan->cap * 8;
+    plan->lds = 2 * stage_bytes(plan->tnq) + plan->tnq * 12 + (kThreads / 64) * 1024;
+    plan->cand_bytes = (size_t)plan->grid * plan->tnq * plan->cap * 8;
     return 0;
 }
 
@@ -469,9 +484,18 @@ hipError_t launch_score_mfma(const void* rows, int dtype, int64_t n, int ld, con
         hipLaunchKernelGGL(kernel, dim3(plan.grid), dim3(kThreads), plan.lds, stream, a);
         return hipGetLastError();
     };
-    if (dtype == 0)
-        return plan.cap == 256 ? launch(&score_topk_mfma_kernel<float, 256>) : launch(&score_topk_mfma_kernel<float, 512>);
-    return plan.cap == 256 ? launch(&score_topk_mfma_kernel<bf16_t, 256>) : launch(&score_topk_mfma_kernel<bf16_t, 512>);
+#define MTR_MFMA_PICK(T)                                                                              \
+    switch (plan.tnq + (plan.cap == 256 ? 0 : 1)) {                                                   \
+        case 32: return launch(&score_topk_mfma_kernel<T, 256, 32>);                                  \
+        case 33: return launch(&score_topk_mfma_kernel<T, 512, 32>);                                  \
+        case 64: return launch(&score_topk_mfma_kernel<T, 256, 64>);                                  \
+        case 65: return launch(&score_topk_mfma_kernel<T, 512, 64>);                                  \
+        case 128: return launch(&score_topk_mfma_kernel<T, 256, 128>);                                \
+        default: return launch(&score_topk_mfma_kernel<T, 512, 128>);                                 \
+    }
+    if (dtype == 0) { MTR_MFMA_PICK(float) }
+    MTR_MFMA_PICK(bf16_t)
+#undef MTR_MFMA_PICK
 }
 
 }  // namespace mtr
