@@ -302,7 +302,10 @@ def test_full_size_properties(native):
 
 
 MFMA_SHAPES = [
-    # n, d, b, k   (bf16 rows whose stride is a multiple of 64 and b >= 3 take the matrix-core kernel)
+    # n, d, b, k   (rows that are a multiple of 128 bytes and b >= 3 take the matrix-core kernel;
+    #               b <= 32 / <= 64 / more select its 32- / 64- / 128-query tiles, k <= 32 the small buffers)
+    (5000, 512, 5, 10),
+    (3000, 320, 31, 40),
     (4097, 768, 40, 10),
     (2500, 1024, 130, 100),
     (1000, 64, 17, 256),
@@ -312,24 +315,26 @@ MFMA_SHAPES = [
 ]
 
 
+@pytest.mark.parametrize("store", ["bf16", "fp32"])
 @pytest.mark.parametrize("n,d,b,k", MFMA_SHAPES)
-def test_matrix_core_path(rag, n, d, b, k):
+def test_matrix_core_path(rag, n, d, b, k, store):
     rng = np.random.default_rng(n + d + b + k)
     corpus = rng.standard_normal((n, d)).astype(np.float32)
     queries = rng.standard_normal((b, d)).astype(np.float32)
     corpus[n // 2] = corpus[1]
     corpus[n - 1] = corpus[1] * 2.0
     queries[0] = corpus[1] * 3.0  # hits the tie set exactly
-    index = rag.PageIndex.from_matrix(corpus, store_dtype="bf16")
+    index = rag.PageIndex.from_matrix(corpus, store_dtype=store)
     idx, score = index.search(queries, k=k)
     s64 = orc.scores(queries, corpus)
-    # rows AND queries are rounded to bf16 here: 1e-3 holds from d of a few hundred; below, the bf16 bound
-    tol = 1e-3 if d >= 256 else 2.0 ** -8
+    # bf16: rows AND queries are rounded, 1e-3 holds from d of a few hundred; below, the bf16 bound.
+    # fp32: the fp32 matrix instruction with blocked summation keeps the scan's 1e-6.
+    tol = 1e-6 if store == "fp32" else 1e-3 if d >= 256 else 2.0 ** -8
     nt = check_topk(idx, score, s64, k, tol)
     # bit-equal stored rows tie exactly: lowest row first
     row = idx[0].tolist()
     assert row[:3] == [1, n // 2, n - 1], row[:5]
-    print(f"mfma {n}x{d} b={b} k={k}: {nt} near-tie differences")
+    print(f"mfma {store} {n}x{d} b={b} k={k}: {nt} near-tie differences")
     index.close()
 
 
