@@ -31,6 +31,22 @@ def top_pages_for_keywords(kw_embeddings_map: dict, pages, top_k: int = 1) -> di
     return {kw: (idx[i], score[i]) for i, (kw, _) in enumerate(usable)}
 
 
+def top_pages_for_texts(keywords: list, model_name: str, device: str, pages, top_k: int = 1, batch_size: int = 64) -> dict:
+    """Encoder and retriever on the same GPU: embeds the keyword texts
+    (pipeline/async_main.py:195), scores them while still in HBM and brings
+    back only the hits.  keyword -> (idx (top_k,), score (top_k,)); {} when
+    there is nothing to embed, the model cannot load or there are no pages."""
+    from .local_rag import embed_queries_device
+    if not keywords or len(pages) == 0:
+        return {}
+    vectors = embed_queries_device(list(keywords), model_name, device, batch_size)
+    if vectors is None:
+        return {}
+    idx, score = search(pages, vectors, k=top_k)
+    idx, score = idx.cpu().numpy(), score.cpu().numpy()
+    return {kw: (idx[i], score[i]) for i, kw in enumerate(keywords)}
+
+
 def local_pages_for_cases(cases, kw_embeddings_map: dict, pages, window_size: int = 1, hits: dict | None = None) -> list:
     """For every case the dict the reference stores as "local_pages_per_keyword"
     (pipeline/utils/retrieval.py:70-76, 82): keyword -> hit page with its

@@ -27,8 +27,8 @@ import numpy as np
 
 from . import _native, index_format
 
-__all__ = ["PageIndex", "load_embeddings", "embed_queries", "retrieve_top_index", "get_surrounding_pages", "search",
-           "configure"]
+__all__ = ["PageIndex", "load_embeddings", "embed_queries", "embed_queries_device", "retrieve_top_index",
+           "get_surrounding_pages", "search", "configure"]
 
 _SETTINGS = {
     "device": int(os.environ.get("MEDTUTOR_RETRIEVAL_DEVICE", os.environ.get("LOCAL_RANK", "0")) or 0),
@@ -105,7 +105,12 @@ class PageIndex(Sequence):
     def search(self, queries, k: int = 10, metric: str = "cosine"):
         """Exact top-k: (idx (B, k) int64 list positions, score (B, k) float32),
         rows ordered by (score desc, position asc); idx[:, 0] is what
-        retrieve_top_index returns for each query."""
+        retrieve_top_index returns for each query.  numpy / list queries give
+        numpy results; a torch tensor already on the shard's GPU (what
+        embed_queries_device returns) is searched in place and gives device
+        tensors, enqueued on torch's current stream without a host round trip."""
+        if type(queries).__module__.startswith("torch") and getattr(queries, "is_cuda", False):
+            return self._shard.search_device(queries.contiguous(), k=k, metric=metric)
         return self._shard.search(queries, k=k, metric=metric)
 
     def top1(self, query_embedding) -> int:
@@ -235,6 +240,17 @@ def pool_and_normalize(last_hidden_state, attention_mask):
     return torch.nn.functional.normalize(summed / counts, p=2, dim=1)
 
 
+def _embed_batches(queries: list, model, tok, device: str, batch_size: int):
+    """Yields the pooled, normalised (b, d) float32 tensor of each batch, on `device`."""
+    import torch
+    with torch.no_grad():
+        for start in range(0, len(queries), batch_size):
+            enc = tok(queries[start:start + batch_size], padding=True, truncation=True, max_length=512,
+                      return_tensors="pt").to(device)
+            hidden = model(**enc).last_hidden_state
+            yield pool_and_normalize(hidden, enc["attention_mask"]).float()
+
+
 def embed_queries(queries: list, model_name: str, device: str, batch_size: int = 64) -> list:
     """One float32 (d,) vector per query text (pipeline/utils/local_rag.py:39-69):
     batches of `batch_size`, truncation at 512 tokens, masked mean pooling, L2
@@ -244,13 +260,21 @@ def embed_queries(queries: list, model_name: str, device: str, batch_size: int =
     model, tok = _encoder_for(model_name, device)
     if model is None or tok is None:
         return [np.array([]) for _ in queries]
-    import torch
     vectors = []
-    with torch.no_grad():
-        for start in range(0, len(queries), batch_size):
-            enc = tok(queries[start:start + batch_size], padding=True, truncation=True, max_length=512,
-                      return_tensors="pt").to(device)
-            hidden = model(**enc).last_hidden_state
-            pooled = pool_and_normalize(hidden, enc["attention_mask"])
-            vectors.extend(v.cpu().numpy() for v in pooled.float())
+    for pooled in _embed_batches(queries, model, tok, device, batch_size):
+        vectors.extend(v.cpu().numpy() for v in pooled)
     return vectors
+
+
+def embed_queries_device(queries: list, model_name: str, device: str = "cuda", batch_size: int = 64):
+    """The same vectors as embed_queries, left on the encoder's device as one
+    (B, d) float32 tensor so that PageIndex.search can score them without a
+    device-to-host-to-device round trip.  None for no queries or when the model
+    cannot load (the caller then has nothing to search with)."""
+    if not queries:
+        return None
+    model, tok = _encoder_for(model_name, device)
+    if model is None or tok is None:
+        return None
+    import torch
+    return torch.cat(list(_embed_batches(queries, model, tok, device, batch_size)), dim=0).contiguous()

@@ -21,6 +21,15 @@ def test_embed_queries_matches_reference(golden):
     np.testing.assert_allclose(np.stack(got2), a["queries_bs2"], atol=1e-6, rtol=0)
 
 
+def test_embed_queries_device_is_the_same_vectors_as_one_tensor(golden):
+    from medical_rag_amd import local_rag as rag
+    a, e = golden("g7_encoder")
+    t = rag.embed_queries_device(e["queries"], TINY, "cpu", batch_size=2)
+    assert tuple(t.shape) == a["queries_bs2"].shape and t.is_contiguous()
+    np.testing.assert_allclose(t.numpy(), a["queries_bs2"], atol=1e-6, rtol=0)
+    assert rag.embed_queries_device([], TINY, "cpu") is None
+
+
 def test_embed_queries_soft_fail_on_bad_model():
     from medical_rag_amd import local_rag as rag
     logging.disable(logging.CRITICAL)

@@ -448,6 +448,33 @@ def test_embed_queries_on_gpu_matches_reference(rag, golden):
     np.testing.assert_allclose(np.stack(got), a["queries_bs64"], atol=2e-5, rtol=0)
 
 
+def test_texts_to_pages_without_leaving_the_gpu(rag, golden):
+    """Keyword texts -> encoder -> pooled vectors -> search, all on the device;
+    same hits as the host route through embed_queries + numpy search."""
+    import os
+    from medical_rag_amd import caller
+    a, e = golden("g7_encoder")
+    tiny = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tiny_encoder")
+    texts = list(e["queries"])
+    d = a["queries_bs64"].shape[1]
+    corpus = np.random.default_rng(8).standard_normal((700, d)).astype(np.float32)
+    corpus[41] = a["queries_bs64"][0]           # a page that is exactly the first keyword's vector
+    index = rag.PageIndex.from_matrix(corpus)
+    dev = rag.embed_queries_device(texts, tiny, "cuda", batch_size=4)
+    assert dev.is_cuda and tuple(dev.shape) == (len(texts), d)
+    np.testing.assert_allclose(dev.cpu().numpy(), a["queries_bs64"], atol=2e-5, rtol=0)
+    di, ds = index.search(dev, k=5)
+    assert di.is_cuda and ds.is_cuda
+    hi, hs = index.search(np.stack(rag.embed_queries(texts, tiny, "cuda", batch_size=4)), k=5)
+    assert (di.cpu().numpy() == hi).all()
+    np.testing.assert_allclose(ds.cpu().numpy(), hs, atol=1e-6, rtol=0)
+    hits = caller.top_pages_for_texts(texts, tiny, "cuda", index, top_k=1, batch_size=4)
+    assert list(hits) == texts and int(hits[texts[0]][0][0]) == 41
+    assert [int(hits[t][0][0]) for t in texts] == hi[:, 0].tolist()
+    assert rag.embed_queries_device([], tiny, "cuda") is None
+    index.close()
+
+
 @pytest.mark.parametrize("store", ["fp32", "bf16"])
 def test_near_duplicate_rows_at_full_width(rag, store):
     """d = 4096 with rows almost parallel to the queries (cosines near 1, so the
