@@ -45,13 +45,21 @@ namespace mtr {
 
 namespace {
 
-constexpr int TM = 128;   // rows per tile
 // Queries per tile are a template parameter TNQ, so that small batches do not
-// pay for 128 columns: 128 (waves 2x2, each 64 rows x 64 queries = 2x2 MFMA
-// tiles), 64 (waves 2x2, each 64 x 32 = 2x1) or 32 (waves 4x1, each 32 x 32).
+// pay for 128 columns.  Tiles of 32 / 64 / 128 queries x 128 rows use four
+// waves: 128 (waves 2x2, each 64 rows x 64 queries = 2x2 MFMA tiles), 64 (waves
+// 2x2, each 64 x 32 = 2x1), 32 (waves 4x1, each 32 x 32).  Large batches take
+// 256 queries x 256 rows with eight waves (2x4, each 128 rows x 64 queries =
+// 4x2 MFMA tiles): per flop that tile moves half the bytes from L2 into LDS,
+// which is what bounds the 128-wide tile.  With only two stage buffers one
+// such workgroup per CU cannot keep enough loads in flight (measured 14.1 ms
+// against 9.7 ms for the 128-wide tile on 1M x 1024, 4096 queries), so it is
+// selected only by MTR_MFMA_TNQ=256 until it gets a deeper load ring.
 constexpr int kStepBytes = 128;  // K bytes of a row per step: 64 bf16 or 32 fp32
-constexpr int kThreads = 256;
-constexpr int stage_bytes(int tnq) { return (TM + tnq) * kStepBytes; }  // row tile then query tile
+constexpr int tile_rows(int tnq) { return tnq == 256 ? 256 : 128; }
+constexpr int tile_threads(int tnq) { return tnq == 256 ? 512 : 256; }
+constexpr int stage_bytes(int tnq) { return (tile_rows(tnq) + tnq) * kStepBytes; }  // row tile then query tile
+constexpr int lds_bytes(int tnq) { return 2 * stage_bytes(tnq) + tnq * 12 + (tile_threads(tnq) / 64) * 1024; }
 
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -80,14 +88,14 @@ struct MfmaArgs {
     int* out_i;
 };
 
-template <int AUX, int ROWS>
+template <int AUX, int ROWS, int WAVES>
 __device__ __forceinline__ void stage_tile(const char* base, long long row0, long long row_max, long long row_bytes,
                                            int k0_bytes, char* lds, int wave, int lane) {
     // ROWS rows x 128 bytes.  One wave instruction fills 8 rows; lane L writes
     // LDS position (row L/8, slot L%8) and fetches chunk (L%8) ^ (L/8) of it.
 #pragma unroll
-    for (int i = 0; i < ROWS / 32; ++i) {
-        const int t = wave * (ROWS / 32) + i;
+    for (int i = 0; i < ROWS / (8 * WAVES); ++i) {
+        const int t = wave * (ROWS / (8 * WAVES)) + i;
         const int r = t * 8 + (lane >> 3);
         long long row = row0 + r;
         row = row < row_max ? row : row_max;
@@ -218,11 +226,17 @@ __device__ __forceinline__ void compact_query(unsigned long long* buf, int c, in
 }
 
 template <typename T, int CAP, int TNQ>
-__global__ __launch_bounds__(kThreads, 2) void score_topk_mfma_kernel(MfmaArgs a) {
+__global__ __launch_bounds__(tile_threads(TNQ), 2) void score_topk_mfma_kernel(MfmaArgs a) {
     constexpr int TN = TNQ;
-    constexpr int MT = TNQ == 32 ? 1 : 2;        // MFMA tiles per wave along the rows
-    constexpr int NT = TNQ == 128 ? 2 : 1;       // ... and along the queries
-    constexpr int QPW = TNQ / 4;                 // queries each wave looks after
+    constexpr int TM = tile_rows(TNQ);
+    constexpr int kThreads = tile_threads(TNQ);
+    constexpr int WAVES = kThreads / 64;
+    constexpr int WN = TNQ == 32 ? 1 : TNQ == 256 ? 4 : 2;  // waves along the queries
+    constexpr int WM = WAVES / WN;                          // ... and along the rows
+    constexpr int MT = TM / (32 * WM);           // MFMA tiles per wave along the rows
+    constexpr int NT = TNQ / (32 * WN);          // ... and along the queries
+    constexpr int QPW = TNQ / WAVES;             // queries each wave looks after
+    static_assert(CAP >= 2 * TM, "a tile may append TM keys per query on top of k + slack kept ones");
     constexpr int kStageBytes = stage_bytes(TNQ);
     constexpr int ROW_AUX = 0;  // default cache policy for the row tiles (non-temporal measured 13-28 % slower)
     constexpr int BK = kStepBytes / (int)sizeof(T);
@@ -238,8 +252,8 @@ __global__ __launch_bounds__(kThreads, 2) void score_topk_mfma_kernel(MfmaArgs a
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int row_off = TNQ == 32 ? wave * 32 : (wave >> 1) * 64;   // the wave's rows inside the tile
-    const int q_off = TNQ == 32 ? 0 : (wave & 1) * (TNQ / 2);       // ... and its queries
+    const int row_off = (wave / WN) * (32 * MT);   // the wave's rows inside the tile
+    const int q_off = (wave % WN) * (32 * NT);     // ... and its queries
 
     // XCD-aware, bijective workgroup remap: ids that land on one XCD become consecutive.
     const int nwg = gridDim.x;
@@ -280,8 +294,8 @@ __global__ __launch_bounds__(kThreads, 2) void score_topk_mfma_kernel(MfmaArgs a
 
     const long long total_steps = my_tiles * ksteps;
     if (total_steps > 0) {
-        stage_tile<ROW_AUX, TM>(a.rows, tile_lo * TM, a.n - 1, row_bytes, 0, stage0, wave, lane);
-        stage_tile<0, TNQ>(qbase, 0, TN - 1, row_bytes, 0, stage0 + TM * kStepBytes, wave, lane);
+        stage_tile<ROW_AUX, TM, WAVES>(a.rows, tile_lo * TM, a.n - 1, row_bytes, 0, stage0, wave, lane);
+        stage_tile<0, TNQ, WAVES>(qbase, 0, TN - 1, row_bytes, 0, stage0 + TM * kStepBytes, wave, lane);
     }
     __syncthreads();
 
@@ -291,12 +305,13 @@ __global__ __launch_bounds__(kThreads, 2) void score_topk_mfma_kernel(MfmaArgs a
         const int cur = (int)(s & 1);
         if (ks == 0 && tid < TN)
             pending_floor = __hip_atomic_load(shared_floor + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (s + 1 < total_steps) {
+        if (s + 1 < total_steps && !(a.debug_no_candidates & 64)) {
             const int nks = ks + 1 == ksteps ? 0 : ks + 1;
             const long long ntile = ks + 1 == ksteps ? tile + 1 : tile;
-            stage_tile<ROW_AUX, TM>(a.rows, ntile * TM, a.n - 1, row_bytes, nks * kStepBytes, stage0 + (cur ^ 1) * kStageBytes, wave, lane);
-            stage_tile<0, TNQ>(qbase, 0, TN - 1, row_bytes, nks * kStepBytes, stage0 + (cur ^ 1) * kStageBytes + TM * kStepBytes, wave, lane);
+            stage_tile<ROW_AUX, TM, WAVES>(a.rows, ntile * TM, a.n - 1, row_bytes, nks * kStepBytes, stage0 + (cur ^ 1) * kStageBytes, wave, lane);
+            stage_tile<0, TNQ, WAVES>(qbase, 0, TN - 1, row_bytes, nks * kStepBytes, stage0 + (cur ^ 1) * kStageBytes + TM * kStepBytes, wave, lane);
         }
+        if (!(a.debug_no_candidates & 32))
         mfma_step<MT, NT>(T{}, stage0 + cur * kStageBytes, stage0 + cur * kStageBytes + TM * kStepBytes, row_off, q_off,
                           lane, acc);
 
@@ -415,6 +430,7 @@ __global__ __launch_bounds__(kThreads, 2) void score_topk_mfma_kernel(MfmaArgs a
 
 }  // namespace
 
+
 int plan_mfma(int dtype, int64_t n, int ld, int b, int k, int num_cus, MfmaPlan* plan) {
     const int esize = dtype == 0 ? 4 : 2;
     if ((ld * esize) % kStepBytes != 0 || ld * esize < 2 * kStepBytes || k < 1 || k > 256 || b < 1 || n < 1) return -1;
@@ -423,18 +439,21 @@ int plan_mfma(int dtype, int64_t n, int ld, int b, int k, int num_cus, MfmaPlan*
         const int c = atoi(e);
         if ((c == 256 || c == 512) && k + 128 <= c) plan->cap = c;
     }
-    plan->slack = (plan->cap - 128 - k) / 4;
-    if (plan->slack > 64) plan->slack = 64;
     plan->tnq = b <= 32 ? 32 : b <= 64 ? 64 : 128;
     if (const char* e = getenv("MTR_MFMA_TNQ")) {
         const int t = atoi(e);
-        if (t == 32 || t == 64 || t == 128) plan->tnq = t;
+        if (t == 32 || t == 64 || t == 128 || (t == 256 && dtype != 0)) plan->tnq = t;
     }
+    const int tm = tile_rows(plan->tnq);
+    if (tm == 256) plan->cap = 512;
+    plan->slack = (plan->cap - tm - k) / 4;
+    if (plan->slack > 64) plan->slack = 64;
     plan->n_qtiles = (b + plan->tnq - 1) / plan->tnq;
-    const long long n_tiles = (n + TM - 1) / TM;
-    // Two workgroups per CU measured best for every tile width: more, shorter
+    const long long n_tiles = (n + tm - 1) / tm;
+    // Two workgroups per CU measured best for every four-wave tile: more, shorter
     // row ranges cost more in top-k selection than they gain in bytes in flight.
-    long long per_cu = 2;
+    // The eight-wave tile fills a CU with one workgroup.
+    long long per_cu = tm == 256 ? 1 : 2;
     if (const char* e = getenv("MTR_MFMA_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
     long long ranges = (per_cu * num_cus + plan->n_qtiles - 1) / plan->n_qtiles;
     if (ranges > n_tiles) ranges = n_tiles;
@@ -442,7 +461,7 @@ int plan_mfma(int dtype, int64_t n, int ld, int b, int k, int num_cus, MfmaPlan*
     plan->tiles_per_range = (n_tiles + ranges - 1) / ranges;
     plan->n_ranges = (int)((n_tiles + plan->tiles_per_range - 1) / plan->tiles_per_range);
     plan->grid = plan->n_qtiles * plan->n_ranges;
-    plan->lds = 2 * stage_bytes(plan->tnq) + plan->tnq * 12 + (kThreads / 64) * 1024;
+    plan->lds = lds_bytes(plan->tnq);
     plan->cand_bytes = (size_t)plan->grid * plan->tnq * plan->cap * 8;
     return 0;
 }
@@ -481,7 +500,7 @@ hipError_t launch_score_mfma(const void* rows, int dtype, int64_t n, int ld, con
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kernel, dim3(plan.grid), dim3(kThreads), plan.lds, stream, a);
+        hipLaunchKernelGGL(kernel, dim3(plan.grid), dim3(tile_threads(plan.tnq)), plan.lds, stream, a);
         return hipGetLastError();
     };
 #define MTR_MFMA_PICK(T)                                                                              \
@@ -494,6 +513,7 @@ hipError_t launch_score_mfma(const void* rows, int dtype, int64_t n, int ld, con
         default: return launch(&score_topk_mfma_kernel<T, 512, 128>);                                 \
     }
     if (dtype == 0) { MTR_MFMA_PICK(float) }
+    if (plan.tnq == 256) return launch(&score_topk_mfma_kernel<bf16_t, 512, 256>);
     MTR_MFMA_PICK(bf16_t)
 #undef MTR_MFMA_PICK
 }
