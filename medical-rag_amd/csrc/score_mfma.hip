@@ -68,6 +68,8 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
 using f32x4v = __attribute__((ext_vector_type(4))) float;
 
+enum { kTilesAll = 0, kTilesEveryNth = 1, kTilesAllButEveryNth = 2 };
+
 struct MfmaArgs {
     const char* rows;        // [n][ld] elements of T
     long long n;
@@ -77,6 +79,11 @@ struct MfmaArgs {
     int n_qtiles;
     int n_ranges;
     long long tiles_per_range;
+    long long n_tiles;       // tiles this launch covers (numbered 0.. in its own order)
+    int tile_mode;           // which tiles of the matrix those are: see MfmaPass
+    int tile_stride;
+    int list_base;           // range r writes candidate list  list_base + r  of  lists_per_query
+    int lists_per_query;
     int k;
     int slack;               // extra keys an in-loop re-selection may keep
     int debug_no_candidates;       // timing experiments only: bit 0 every floor starts at +inf; bit 1 appends wrap, no re-selection; bit 2 count events
@@ -84,7 +91,7 @@ struct MfmaArgs {
     float debug_floor;                   // bit 4: every own floor starts here
     unsigned long long* cand_buf;  // [grid][TN][CAP]
     unsigned int* shared_floor;    // [n_qtiles*TN] order-preserving score bits, zeroed before the launch
-    float* out_s;            // [b][n_ranges][k]
+    float* out_s;            // [b][lists_per_query][k]
     int* out_i;
 };
 
@@ -263,12 +270,18 @@ __global__ __launch_bounds__(tile_threads(TNQ), 2) void score_topk_mfma_kernel(M
     const int qt = wgid / a.n_ranges;
     const int range = wgid % a.n_ranges;
 
-    const long long n_tiles = (a.n + TM - 1) / TM;
+    const long long n_tiles = a.n_tiles;
     const long long tile_lo = (long long)range * a.tiles_per_range;
     long long tile_hi = tile_lo + a.tiles_per_range;
     if (tile_hi > n_tiles) tile_hi = n_tiles;
     const long long my_tiles = tile_hi > tile_lo ? tile_hi - tile_lo : 0;
     const int ksteps = a.ld / BK;
+    // Tile t of this launch is tile phys(t) of the matrix (increasing in t).
+    auto phys = [&](long long t) -> long long {
+        if (a.tile_mode == kTilesEveryNth) return t * a.tile_stride;
+        if (a.tile_mode == kTilesAllButEveryNth) return t + t / (a.tile_stride - 1) + 1;
+        return t;
+    };
     const long long row_bytes = (long long)a.ld * (long long)sizeof(T);
 
     for (int i = tid; i < TN; i += kThreads) {
@@ -277,7 +290,9 @@ __global__ __launch_bounds__(tile_threads(TNQ), 2) void score_topk_mfma_kernel(M
         floor_lds[i] = (qg < a.b && !(a.debug_no_candidates & 1)) ? ((a.debug_no_candidates & 16) ? a.debug_floor : -__builtin_huge_valf())
                                                                  : __builtin_huge_valf();
         cnt_lds[i] = 0;
-        shared_lds[i] = -__builtin_huge_valf();
+        // floors known before the launch (from a sample of the rows) or already published by faster ranges
+        const unsigned int known = __hip_atomic_load(a.shared_floor + (size_t)qt * TN + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        shared_lds[i] = unorder_f32(known | (known == 0 ? 0x007fffffu : 0u));
     }
     unsigned int* shared_floor = a.shared_floor + (size_t)qt * TN;
     unsigned int pending_floor = 0;  // threads < TN: the shared floor word fetched at the start of a tile
@@ -294,12 +309,13 @@ __global__ __launch_bounds__(tile_threads(TNQ), 2) void score_topk_mfma_kernel(M
 
     const long long total_steps = my_tiles * ksteps;
     if (total_steps > 0) {
-        stage_tile<ROW_AUX, TM, WAVES>(a.rows, tile_lo * TM, a.n - 1, row_bytes, 0, stage0, wave, lane);
+        stage_tile<ROW_AUX, TM, WAVES>(a.rows, phys(tile_lo) * TM, a.n - 1, row_bytes, 0, stage0, wave, lane);
         stage_tile<0, TNQ, WAVES>(qbase, 0, TN - 1, row_bytes, 0, stage0 + TM * kStepBytes, wave, lane);
     }
     __syncthreads();
 
     long long tile = tile_lo;
+    long long ptile = phys(tile_lo), ptile_next = phys(tile_lo + 1);
     int ks = 0;
     for (long long s = 0; s < total_steps; ++s) {
         const int cur = (int)(s & 1);
@@ -307,7 +323,7 @@ __global__ __launch_bounds__(tile_threads(TNQ), 2) void score_topk_mfma_kernel(M
             pending_floor = __hip_atomic_load(shared_floor + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (s + 1 < total_steps && !(a.debug_no_candidates & 64)) {
             const int nks = ks + 1 == ksteps ? 0 : ks + 1;
-            const long long ntile = ks + 1 == ksteps ? tile + 1 : tile;
+            const long long ntile = ks + 1 == ksteps ? ptile_next : ptile;
             stage_tile<ROW_AUX, TM, WAVES>(a.rows, ntile * TM, a.n - 1, row_bytes, nks * kStepBytes, stage0 + (cur ^ 1) * kStageBytes, wave, lane);
             stage_tile<0, TNQ, WAVES>(qbase, 0, TN - 1, row_bytes, nks * kStepBytes, stage0 + (cur ^ 1) * kStageBytes + TM * kStepBytes, wave, lane);
         }
@@ -318,8 +334,8 @@ __global__ __launch_bounds__(tile_threads(TNQ), 2) void score_topk_mfma_kernel(M
         const bool tile_done = ks + 1 == ksteps;
         if (tile_done) {
             // Scores of the 128-row x TNQ-query tile are complete: append what clears each query's floor.
-            const long long row_base = tile * TM + row_off + 4 * (lane >> 5);
-            const bool last_tile = (tile + 1) * TM > a.n;
+            const long long row_base = ptile * TM + row_off + 4 * (lane >> 5);
+            const bool last_tile = (ptile + 1) * TM > a.n;
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 const int ql = q_off + n * 32 + (lane & 31);
@@ -350,7 +366,9 @@ __global__ __launch_bounds__(tile_threads(TNQ), 2) void score_topk_mfma_kernel(M
                             if (a.debug_no_candidates & 4) atomicAdd(a.debug_counters, (unsigned long long)np);
                         }
                         // Registers any lane wants to store, as a wave-uniform mask: the
-                        // sixteen tests below are then scalar branches.
+                        // sixteen tests below are then scalar branches.  (Letting every
+                        // lane walk its own passing rows instead, with a select tree to
+                        // fetch element r, measured 5-15 % slower at every batch size.)
                         unsigned int any_r = pass;
 #pragma unroll
                         for (int off = 32; off >= 1; off >>= 1) any_r |= __shfl_xor(any_r, off, 64);
@@ -392,6 +410,8 @@ __global__ __launch_bounds__(tile_threads(TNQ), 2) void score_topk_mfma_kernel(M
             }
             ks = 0;
             ++tile;
+            ptile = ptile_next;
+            ptile_next = phys(tile + 1);
             if (ksteps == 1) __syncthreads();  // no other barrier separates this from the next tile's appends
         } else {
             ++ks;
@@ -413,8 +433,8 @@ __global__ __launch_bounds__(tile_threads(TNQ), 2) void score_topk_mfma_kernel(M
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             cq = __builtin_amdgcn_readfirstlane(cnt_lds[q]);
         }
-        float* os = a.out_s + ((size_t)qg * a.n_ranges + range) * a.k;
-        int* oi = a.out_i + ((size_t)qg * a.n_ranges + range) * a.k;
+        float* os = a.out_s + ((size_t)qg * a.lists_per_query + a.list_base + range) * a.k;
+        int* oi = a.out_i + ((size_t)qg * a.lists_per_query + a.list_base + range) * a.k;
         for (int i = lane; i < a.k; i += 64) {
             if (i < cq) {
                 const unsigned long long key = buf[i];
@@ -449,7 +469,9 @@ int plan_mfma(int dtype, int64_t n, int ld, int b, int k, int num_cus, MfmaPlan*
     plan->slack = (plan->cap - tm - k) / 4;
     if (plan->slack > 64) plan->slack = 64;
     plan->n_qtiles = (b + plan->tnq - 1) / plan->tnq;
+    plan->tm = tm;
     const long long n_tiles = (n + tm - 1) / tm;
+    plan->n_tiles = n_tiles;
     // Two workgroups per CU measured best for every four-wave tile: more, shorter
     // row ranges cost more in top-k selection than they gain in bytes in flight.
     // The eight-wave tile fills a CU with one workgroup.
@@ -467,8 +489,8 @@ int plan_mfma(int dtype, int64_t n, int ld, int b, int k, int num_cus, MfmaPlan*
 }
 
 hipError_t launch_score_mfma(const void* rows, int dtype, int64_t n, int ld, const void* queries, int b, int k,
-                             const MfmaPlan& plan, void* cand_buf, unsigned int* shared_floor, float* out_s,
-                             int* out_i, hipStream_t stream) {
+                             const MfmaPlan& plan, const MfmaPass& pass, void* cand_buf, unsigned int* shared_floor,
+                             float* out_s, int* out_i, hipStream_t stream) {
     MfmaArgs a;
     a.rows = static_cast<const char*>(rows);
     a.n = n;
@@ -478,6 +500,11 @@ hipError_t launch_score_mfma(const void* rows, int dtype, int64_t n, int ld, con
     a.n_qtiles = plan.n_qtiles;
     a.n_ranges = plan.n_ranges;
     a.tiles_per_range = plan.tiles_per_range;
+    a.n_tiles = plan.n_tiles;
+    a.tile_mode = pass.tile_mode;
+    a.tile_stride = pass.tile_stride;
+    a.list_base = pass.list_base;
+    a.lists_per_query = pass.lists_per_query;
     a.k = k;
     a.slack = plan.slack;
     a.debug_no_candidates = getenv("MTR_MFMA_DEBUG") ? atoi(getenv("MTR_MFMA_DEBUG")) : 0;
@@ -516,6 +543,27 @@ hipError_t launch_score_mfma(const void* rows, int dtype, int64_t n, int ld, con
     if (plan.tnq == 256) return launch(&score_topk_mfma_kernel<bf16_t, 512, 256>);
     MTR_MFMA_PICK(bf16_t)
 #undef MTR_MFMA_PICK
+}
+
+namespace {
+__global__ void floor_from_sample_kernel(const float* kth_score, long long stride, int b, unsigned int* shared_floor,
+                                         int n_words) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_words) return;
+    unsigned int bits = 0;  // 0 = no floor known
+    if (q < b) {
+        const float s = kth_score[(long long)q * stride];
+        if (s > -__builtin_huge_valf()) bits = order_f32(s);
+    }
+    shared_floor[q] = bits;
+}
+}  // namespace
+
+hipError_t launch_floor_from_sample(const float* kth_score, long long stride, int b, unsigned int* shared_floor,
+                                    int n_words, hipStream_t stream) {
+    hipLaunchKernelGGL(floor_from_sample_kernel, dim3((n_words + 255) / 256), dim3(256), 0, stream, kth_score, stride, b,
+                       shared_floor, n_words);
+    return hipGetLastError();
 }
 
 }  // namespace mtr

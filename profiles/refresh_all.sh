@@ -1,0 +1,17 @@
+#!/bin/bash
+# Regenerates this round's committed measurements on the GPU box (run from the
+# repo root): kernel-trace stats + bench line per workload, PMC traffic, sweeps.
+set -e
+R=${1:-r01}
+for wl in c4 c2 c3 c1 c5shard; do
+  extra=""; [ $wl = c4 ] || extra="--no-cpu-baseline"
+  steps=50; [ $wl = c3 ] && steps=10
+  profiles/run_prof.sh $wl --workload $wl --steps $steps --warmup 5 $extra > gpurun_out/prof_$wl.txt
+  cp gpurun_out/prof/${wl}_kernel_stats.csv gpurun_out/${R}_${wl}_kernel_stats.csv
+  timeout -k 10 300 python3 bench.py --workload $wl --steps $steps --warmup 5 $extra > gpurun_out/${R}_${wl}_bench.json
+  echo "$wl done"
+done
+timeout -k 10 600 python3 profiles/collect_pmc_traffic.py gpurun_out/${R}_pmc_traffic.json
+timeout -k 10 200 python3 profiles/sweep_batch.py 1000000 1024 bf16 10 > gpurun_out/${R}_sweep_bf16_1Mx1024.json
+timeout -k 10 200 python3 profiles/sweep_batch.py 1000000 768 fp32 10 > gpurun_out/${R}_sweep_fp32_1Mx768.json
+echo all done

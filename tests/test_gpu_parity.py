@@ -358,6 +358,40 @@ def test_matrix_core_matches_scan(native):
     shard.close()
 
 
+@pytest.mark.parametrize("store", ["bf16", "fp32"])
+@pytest.mark.parametrize("stride", [2, 5, 16])
+def test_sampled_two_launch_search_equals_single_launch(native, store, stride):
+    """Large shards are searched as two launches (every stride-th row tile
+    first, its k-th best scores as the floors of the rest).  Forced here on a
+    small shard: the result must be identical to the single launch, ties and a
+    ragged last tile included."""
+    import os
+    rng = np.random.default_rng(500 + stride)
+    n, d, b, k = 128 * 67 + 45, 256, 37, 24
+    corpus = rng.standard_normal((n, d)).astype(np.float32)
+    queries = rng.standard_normal((b, d)).astype(np.float32)
+    # exact ties across sampled and other tiles, one of them in the ragged last tile
+    for row in (128 * stride + 3, 128 * (stride + 1) + 9, n - 2):
+        corpus[row] = corpus[5]
+    queries[0] = corpus[5]
+    shard = native.DeviceShard.from_host(corpus, store_dtype=store)
+    old = os.environ.get("MTR_MFMA_SAMPLE_STRIDE")
+    try:
+        os.environ["MTR_MFMA_SAMPLE_STRIDE"] = "0"
+        one_i, one_s = shard.search(queries, k=k)
+        os.environ["MTR_MFMA_SAMPLE_STRIDE"] = str(stride)
+        two_i, two_s = shard.search(queries, k=k)
+    finally:
+        if old is None:
+            os.environ.pop("MTR_MFMA_SAMPLE_STRIDE", None)
+        else:
+            os.environ["MTR_MFMA_SAMPLE_STRIDE"] = old
+    assert (one_i == two_i).all() and (one_s == two_s).all()
+    assert one_i[0, :4].tolist() == [5, 128 * stride + 3, 128 * (stride + 1) + 9, n - 2]
+    check_topk(two_i, two_s, orc.scores(queries, corpus), k, 1e-6 if store == "fp32" else 2.0 ** -8)
+    shard.close()
+
+
 def test_merge_reads_packed_gathered_buffer(native):
     """The exchange buffer layout of the multi-GPU path: every rank's ids and
     scores in one block, merged through strided views without copies."""
