@@ -99,7 +99,7 @@ struct mtr_index {
     DevBuf q_bf16;     // query tiles (storage type) for the matrix-core kernel
     DevBuf mfma_cand;  // its workgroups' candidate buffers
     DevBuf mfma_floor; // per-query floor shared by the row ranges
-    DevBuf samp_i, samp_s;  // best k of the sampled tiles per query
+    DevBuf tile_max;   // the sampling launch's best score per (query, sampled tile)
     DevBuf out_i, out_s;
     DevBuf stage;      // staging for host rows
     void* pinned = nullptr;
@@ -136,57 +136,56 @@ int mfma_min_batch(int dtype) {
     return 3;
 }
 
-// Every how many row tiles one goes into the sample launch (< 2: no sample).
-// The sample launch starts without floors, so its cost grows with its size;
-// what the second launch appends shrinks as k * n / sample.  The two balance
-// at a sample of about 5 * sqrt(k * n) rows (measured on 1M and 12.5M rows, k
-// 10 and 100: stride 64 best for k = 10, 16-32 for k = 100 at 1M rows).
-constexpr int kMinSampleTiles = 8;
+// Every how many row tiles one goes into the sampling launch (< 2: no sample).
+// The sample costs 1/stride of a full launch; what the full launch appends
+// shrinks as k * n / sample.  A sample of about 5 * sqrt(k * n) rows balanced
+// the two on 1M and 12.5M rows at k 10 and 100.  The sample needs at least 2k
+// tiles (its floor is the k-th largest per-tile best score) and at most
+// kMaxSampleTiles.
 constexpr double kMinTwoPassBytes = 1.0e9;
 int forced_sample_stride() {  // read on every search, so that tests can switch it
     const char* e = getenv("MTR_MFMA_SAMPLE_STRIDE");
     return e ? atoi(e) : -1;
 }
-int sample_stride(long long n, int k) {
+int sample_stride(long long n, long long n_tiles, int k) {
     const int forced = forced_sample_stride();
-    if (forced >= 0) return forced;
-    const int s = (int)(std::sqrt((double)n / (double)k) / 5.0);
-    return std::min(256, std::max(4, s));
+    long long s = forced >= 0 ? forced : (long long)(std::sqrt((double)n / (double)k) / 5.0);
+    if (forced < 0) s = std::min<long long>(1024, std::max<long long>(4, s));
+    if (s < 2) return 0;
+    s = std::max(s, (n_tiles + mtr::kMaxSampleTiles - 1) / mtr::kMaxSampleTiles);
+    s = std::min(s, n_tiles / (2LL * k));
+    return s >= 2 ? (int)s : 0;
 }
 
 // Matrix-core path: queries converted to the shard's type, fused score + top-k
-// launch(es), then the merge of the per-range lists.
-int enqueue_mfma(mtr_index* ix, const mtr::MfmaPlan& full, const void* dev_queries, int q_dtype, int b, int k,
+// launch, then the merge of the per-range lists.
+int enqueue_mfma(mtr_index* ix, const mtr::MfmaPlan& plan, const void* dev_queries, int q_dtype, int b, int k,
                  int metric, long long* dev_out_idx, float* dev_out_score, hipStream_t stream) {
     int rc;
-    // Large shards run as two launches.  Every sample_stride()-th row tile is
-    // scored first; the k-th best score each query reaches on that sample is a
-    // lower bound of its final k-th best, so the launch over the other tiles
-    // starts with that floor instead of collecting (and re-selecting) every
-    // early row.  Both launches leave per-range candidate lists side by side
-    // and one merge finishes the job.
-    const int stride = sample_stride(ix->n, k);
-    const long long n_tiles = full.n_tiles;
-    // The extra launches and the sample's own cold start cost about 0.1 ms: not
-    // worth it on shards that a single launch scores in a few tenths of a ms.
+    // Large shards get a sampling launch first: every stride-th row tile is
+    // scored and only each query's best score per tile is kept.  The k-th
+    // largest of those is a lower bound of the query's final k-th best score
+    // (k different rows reach it), so the full launch starts from that floor
+    // instead of collecting and re-selecting the first tiles of every row range.
+    // The extra launches cost about 0.05 ms: not worth it on shards that one
+    // launch scores in a few tenths of a ms.
     const bool big = forced_sample_stride() >= 0 ||
                      (double)ix->n * ix->ld * dtype_size(ix->dtype) >= kMinTwoPassBytes;
-    const bool two_pass = big && stride >= 2 && n_tiles >= (long long)stride * kMinSampleTiles;
-    mtr::MfmaPlan samp = full, rest = full;
-    if (two_pass) {
-        const long long n_samp = (n_tiles + stride - 1) / stride;
-        if (mtr::plan_mfma(ix->dtype, n_samp * full.tm, ix->ld, b, k, ix->num_cus, &samp) != 0 ||
-            mtr::plan_mfma(ix->dtype, (n_tiles - n_samp) * full.tm, ix->ld, b, k, ix->num_cus, &rest) != 0)
-            return fail(MTR_ERR_INVALID, "internal: no launch shape for the sampled passes");
+    const int stride = big ? sample_stride(ix->n, plan.n_tiles, k) : 0;
+    mtr::MfmaPlan samp = plan;
+    if (stride >= 2) {
+        const long long n_samp = (plan.n_tiles + stride - 1) / stride;
+        if (mtr::plan_mfma(ix->dtype, n_samp * plan.tm, ix->ld, b, k, ix->num_cus, &samp) != 0)
+            return fail(MTR_ERR_INVALID, "internal: no launch shape for the sampling launch");
     }
-    const int n_lists = two_pass ? samp.n_ranges + rest.n_ranges : full.n_ranges;
-    const size_t qbytes = (size_t)full.n_qtiles * full.tnq * ix->ld * dtype_size(ix->dtype);
+    const size_t qbytes = (size_t)plan.n_qtiles * plan.tnq * ix->ld * dtype_size(ix->dtype);
     if ((rc = ix->q_bf16.reserve(qbytes)) != MTR_OK) return rc;
-    if ((rc = ix->mfma_cand.reserve(std::max(full.cand_bytes, std::max(samp.cand_bytes, rest.cand_bytes)))) != MTR_OK) return rc;
-    if ((rc = ix->cand_s.reserve((size_t)b * n_lists * k * 4)) != MTR_OK) return rc;
-    if ((rc = ix->cand_i.reserve((size_t)b * n_lists * k * 4)) != MTR_OK) return rc;
-    const int floor_words = full.n_qtiles * full.tnq;
+    if ((rc = ix->mfma_cand.reserve(plan.cand_bytes)) != MTR_OK) return rc;
+    if ((rc = ix->cand_s.reserve((size_t)b * plan.n_ranges * k * 4)) != MTR_OK) return rc;
+    if ((rc = ix->cand_i.reserve((size_t)b * plan.n_ranges * k * 4)) != MTR_OK) return rc;
+    const int floor_words = plan.n_qtiles * plan.tnq;
     if ((rc = ix->mfma_floor.reserve((size_t)floor_words * 4)) != MTR_OK) return rc;
+    if (stride >= 2 && (rc = ix->tile_max.reserve((size_t)floor_words * samp.n_tiles * 4)) != MTR_OK) return rc;
     HIP_TRY(hipMemsetAsync(ix->mfma_floor.p, 0, (size_t)floor_words * 4, stream));
     HIP_TRY(hipMemsetAsync(ix->q_bf16.p, 0, qbytes, stream));
     HIP_TRY(mtr::launch_load_rows(dev_queries, q_dtype, b, ix->d, ix->q_bf16.p, ix->dtype, ix->ld,
@@ -207,29 +206,20 @@ int enqueue_mfma(mtr_index* ix, const mtr::MfmaPlan& full, const void* dev_queri
     unsigned int* floors = static_cast<unsigned int*>(ix->mfma_floor.p);
     float* lists_s = static_cast<float*>(ix->cand_s.p);
     int* lists_i = static_cast<int*>(ix->cand_i.p);
-    if (two_pass) {
-        if ((rc = ix->samp_i.reserve((size_t)b * k * 8)) != MTR_OK) return rc;
-        if ((rc = ix->samp_s.reserve((size_t)b * k * 4)) != MTR_OK) return rc;
-        const mtr::MfmaPass p1{1, stride, 0, n_lists};
-        HIP_TRY(mtr::launch_score_mfma(ix->rows, ix->dtype, ix->n, ix->ld, ix->q_bf16.p, b, k, samp, p1, ix->mfma_cand.p,
-                                       floors, lists_s, lists_i, stream));
-        // best k of the sample per query; its last score is the floor of the second launch
-        float* samp_s = static_cast<float*>(ix->samp_s.p);
-        HIP_TRY(mtr::launch_merge_topk(lists_s, lists_i, nullptr, samp.n_ranges, (long long)k, (long long)k,
-                                       (long long)n_lists * k, k, b, k, 0, static_cast<long long*>(ix->samp_i.p), samp_s,
-                                       stream));
-        HIP_TRY(mtr::launch_floor_from_sample(samp_s + (k - 1), k, b, floors, floor_words, stream));
-        const mtr::MfmaPass p2{2, stride, samp.n_ranges, n_lists};
-        HIP_TRY(mtr::launch_score_mfma(ix->rows, ix->dtype, ix->n, ix->ld, ix->q_bf16.p, b, k, rest, p2, ix->mfma_cand.p,
-                                       floors, lists_s, lists_i, stream));
-    } else {
-        const mtr::MfmaPass all{0, 0, 0, n_lists};
-        HIP_TRY(mtr::launch_score_mfma(ix->rows, ix->dtype, ix->n, ix->ld, ix->q_bf16.p, b, k, full, all, ix->mfma_cand.p,
-                                       floors, lists_s, lists_i, stream));
+    if (stride >= 2) {
+        unsigned int* tile_max = static_cast<unsigned int*>(ix->tile_max.p);
+        const mtr::MfmaPass sampling{stride, tile_max};
+        HIP_TRY(mtr::launch_score_mfma(ix->rows, ix->dtype, ix->n, ix->ld, ix->q_bf16.p, b, k, samp, sampling,
+                                       ix->mfma_cand.p, floors, lists_s, lists_i, stream));
+        HIP_TRY(mtr::launch_floor_from_tile_max(tile_max, (int)samp.n_tiles, b, k, floors, stream));
     }
+    const mtr::MfmaPass all{1, nullptr};
+    HIP_TRY(mtr::launch_score_mfma(ix->rows, ix->dtype, ix->n, ix->ld, ix->q_bf16.p, b, k, plan, all, ix->mfma_cand.p,
+                                   floors, lists_s, lists_i, stream));
     if (ix->profiling) HIP_TRY(hipEventRecord(e1, stream));
-    HIP_TRY(mtr::launch_merge_topk(lists_s, lists_i, nullptr, n_lists, (long long)k, (long long)k, (long long)n_lists * k, k,
-                                   b, k, ix->row_offset, dev_out_idx, dev_out_score, stream));
+    HIP_TRY(mtr::launch_merge_topk(lists_s, lists_i, nullptr, plan.n_ranges, (long long)k, (long long)k,
+                                   (long long)plan.n_ranges * k, k, b, k, ix->row_offset, dev_out_idx, dev_out_score,
+                                   stream));
     return MTR_OK;
 }
 
@@ -548,8 +538,7 @@ void mtr_index_destroy(mtr_index_t* ix) {
         ix->q_bf16.release();
         ix->mfma_cand.release();
         ix->mfma_floor.release();
-        ix->samp_i.release();
-        ix->samp_s.release();
+        ix->tile_max.release();
         ix->out_i.release();
         ix->out_s.release();
         ix->stage.release();

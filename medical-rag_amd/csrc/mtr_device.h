@@ -107,31 +107,30 @@ struct MfmaPlan {
 // covered (row stride not a multiple of 128 bytes or shorter than 256, or k > 256).
 int plan_mfma(int dtype, int64_t n, int ld, int b, int k, int num_cus, MfmaPlan* plan);
 
-// Which row tiles of the matrix one launch covers and where its candidate
-// lists go.  A search may run as two launches: every tile_stride-th tile first
-// (tile_mode 1), whose merged k-th best scores become the starting floors
-// (launch_floor_from_sample) of the launch over all the other tiles
-// (tile_mode 2); tile_mode 0 covers every tile in one launch.
+// Which row tiles of the matrix one launch covers and what it keeps.  Large
+// shards are searched in two launches: a sampling launch over every
+// tile_stride-th tile that only records each query's best score per tile
+// (tile_max), whose k-th largest per query (launch_floor_from_tile_max) is a
+// valid starting floor for the full launch (tile_stride 1, tile_max NULL).
+constexpr int kMaxSampleTiles = 1024;
 struct MfmaPass {
-    int tile_mode;
     int tile_stride;
-    int list_base;            // the launch's range r writes list  list_base + r ...
-    int lists_per_query;      // ... of this many per query
+    unsigned int* tile_max;   // [n_qtiles*tnq][plan.n_tiles] order-preserving score bits, or NULL
 };
 
 // rows x queries on the matrix cores with fused top-k, both in the shard's storage type
 // (dtype 0 fp32: exact-fp32 MFMA; 2 bf16).  queries:
 // [n_qtiles*tnq][ld], rows past b zero.  shared_floor: n_qtiles*tnq words, zeroed by the
-// caller or preset by launch_floor_from_sample before every launch.  plan: from plan_mfma for the
-// number of rows the pass covers (its tiles x plan.tm).  Outputs
-// [b][pass.lists_per_query][k] candidate lists (unsorted, padded with (-inf, -1)).
+// caller or preset by launch_floor_from_tile_max before every launch.  plan: from plan_mfma for the
+// number of rows the pass covers (its tiles x plan.tm).  Outputs (tile_max NULL)
+// [b][n_ranges][k] candidate lists (unsorted, padded with (-inf, -1)).
 hipError_t launch_score_mfma(const void* rows, int dtype, int64_t n, int ld, const void* queries, int b, int k,
                              const MfmaPlan& plan, const MfmaPass& pass, void* cand_buf, unsigned int* shared_floor,
                              float* out_s, int* out_i, hipStream_t stream);
 
-// shared_floor[q] = order-preserving bits of kth_score[q * stride] for q < b (0 = none when
-// that score is -inf or q >= b), for all n_words words.
-hipError_t launch_floor_from_sample(const float* kth_score, long long stride, int b, unsigned int* shared_floor,
-                                    int n_words, hipStream_t stream);
+// shared_floor[q] = k-th largest of tile_max[q][0..n_tiles) for q < b (0 when there are not
+// more than k tiles); n_tiles <= kMaxSampleTiles.
+hipError_t launch_floor_from_tile_max(const unsigned int* tile_max, int n_tiles, int b, int k,
+                                      unsigned int* shared_floor, hipStream_t stream);
 
 }  // namespace mtr

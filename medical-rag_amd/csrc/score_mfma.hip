@@ -68,8 +68,6 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
 using f32x4v = __attribute__((ext_vector_type(4))) float;
 
-enum { kTilesAll = 0, kTilesEveryNth = 1, kTilesAllButEveryNth = 2 };
-
 struct MfmaArgs {
     const char* rows;        // [n][ld] elements of T
     long long n;
@@ -80,10 +78,8 @@ struct MfmaArgs {
     int n_ranges;
     long long tiles_per_range;
     long long n_tiles;       // tiles this launch covers (numbered 0.. in its own order)
-    int tile_mode;           // which tiles of the matrix those are: see MfmaPass
-    int tile_stride;
-    int list_base;           // range r writes candidate list  list_base + r  of  lists_per_query
-    int lists_per_query;
+    int tile_stride;         // tile t of the launch is tile t * tile_stride of the matrix
+    unsigned int* tile_max;  // not NULL: only record every query's best score per tile, [n_qtiles*TN][n_tiles]
     int k;
     int slack;               // extra keys an in-loop re-selection may keep
     int debug_no_candidates;       // timing experiments only: bit 0 every floor starts at +inf; bit 1 appends wrap, no re-selection; bit 2 count events
@@ -91,7 +87,7 @@ struct MfmaArgs {
     float debug_floor;                   // bit 4: every own floor starts here
     unsigned long long* cand_buf;  // [grid][TN][CAP]
     unsigned int* shared_floor;    // [n_qtiles*TN] order-preserving score bits, zeroed before the launch
-    float* out_s;            // [b][lists_per_query][k]
+    float* out_s;            // [b][n_ranges][k]
     int* out_i;
 };
 
@@ -232,7 +228,10 @@ __device__ __forceinline__ void compact_query(unsigned long long* buf, int c, in
     finish_select<E>(buf, key, k, slack, floor_lds, cnt_lds, q, lane, shared_floor_q, hist);
 }
 
-template <typename T, int CAP, int TNQ>
+// MAX_ONLY: the sampling form, which keeps nothing but each query's best score
+// per tile (a.tile_max).  A compile-time switch: as a run-time branch it made
+// the compiler copy all accumulators after every K step.
+template <typename T, int CAP, int TNQ, bool MAX_ONLY>
 __global__ __launch_bounds__(tile_threads(TNQ), 2) void score_topk_mfma_kernel(MfmaArgs a) {
     constexpr int TN = TNQ;
     constexpr int TM = tile_rows(TNQ);
@@ -277,11 +276,8 @@ __global__ __launch_bounds__(tile_threads(TNQ), 2) void score_topk_mfma_kernel(M
     const long long my_tiles = tile_hi > tile_lo ? tile_hi - tile_lo : 0;
     const int ksteps = a.ld / BK;
     // Tile t of this launch is tile phys(t) of the matrix (increasing in t).
-    auto phys = [&](long long t) -> long long {
-        if (a.tile_mode == kTilesEveryNth) return t * a.tile_stride;
-        if (a.tile_mode == kTilesAllButEveryNth) return t + t / (a.tile_stride - 1) + 1;
-        return t;
-    };
+    auto phys = [&](long long t) -> long long { return t * a.tile_stride; };
+    unsigned int* best_lds = reinterpret_cast<unsigned int*>(cnt_lds);  // max_only: best score of the tile per query
     const long long row_bytes = (long long)a.ld * (long long)sizeof(T);
 
     for (int i = tid; i < TN; i += kThreads) {
@@ -332,7 +328,24 @@ __global__ __launch_bounds__(tile_threads(TNQ), 2) void score_topk_mfma_kernel(M
                           lane, acc);
 
         const bool tile_done = ks + 1 == ksteps;
-        if (tile_done) {
+        if constexpr (MAX_ONLY) { if (tile_done) {
+            // Sampling launch: keep nothing but the tile's best score per query.  Rows
+            // past the end of the matrix were staged as copies of the last row, so
+            // they cannot raise a maximum.
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                float mx = -__builtin_huge_valf();
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        mx = fmaxf(mx, acc[m][n][r]);
+                        acc[m][n][r] = 0.f;
+                    }
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                if (lane < 32) atomicMax(&best_lds[q_off + n * 32 + lane], order_f32(mx));
+            }
+        } } else if (tile_done) {
             // Scores of the 128-row x TNQ-query tile are complete: append what clears each query's floor.
             const long long row_base = ptile * TM + row_off + 4 * (lane >> 5);
             const bool last_tile = (ptile + 1) * TM > a.n;
@@ -392,7 +405,17 @@ __global__ __launch_bounds__(tile_threads(TNQ), 2) void score_topk_mfma_kernel(M
             }
         }
         __syncthreads();
-        if (tile_done) {
+        if (MAX_ONLY && tile_done) {
+            if (tid < TN) {
+                a.tile_max[((size_t)qt * TN + tid) * a.n_tiles + tile] = best_lds[tid];
+                best_lds[tid] = 0u;
+            }
+            ks = 0;
+            ++tile;
+            ptile = ptile_next;
+            ptile_next = phys(tile + 1);
+            __syncthreads();  // the next tile's maxima start from the cleared words
+        } else if (tile_done) {
             // Wave w looks after queries [QPW*w, QPW*(w+1)): re-select any whose buffer
             // could overflow on the next tile (a tile adds at most TM entries).
             if (tid < TN) shared_lds[tid] = unorder_f32(pending_floor | (pending_floor == 0 ? 0x007fffffu : 0u));
@@ -418,6 +441,7 @@ __global__ __launch_bounds__(tile_threads(TNQ), 2) void score_topk_mfma_kernel(M
         }
     }
 
+    if constexpr (MAX_ONLY) return;
     // Final selection per query and one candidate list per (query, range).
     __syncthreads();
     for (int j = 0; j < QPW; ++j) {
@@ -433,8 +457,8 @@ __global__ __launch_bounds__(tile_threads(TNQ), 2) void score_topk_mfma_kernel(M
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             cq = __builtin_amdgcn_readfirstlane(cnt_lds[q]);
         }
-        float* os = a.out_s + ((size_t)qg * a.lists_per_query + a.list_base + range) * a.k;
-        int* oi = a.out_i + ((size_t)qg * a.lists_per_query + a.list_base + range) * a.k;
+        float* os = a.out_s + ((size_t)qg * a.n_ranges + range) * a.k;
+        int* oi = a.out_i + ((size_t)qg * a.n_ranges + range) * a.k;
         for (int i = lane; i < a.k; i += 64) {
             if (i < cq) {
                 const unsigned long long key = buf[i];
@@ -501,10 +525,8 @@ hipError_t launch_score_mfma(const void* rows, int dtype, int64_t n, int ld, con
     a.n_ranges = plan.n_ranges;
     a.tiles_per_range = plan.tiles_per_range;
     a.n_tiles = plan.n_tiles;
-    a.tile_mode = pass.tile_mode;
-    a.tile_stride = pass.tile_stride;
-    a.list_base = pass.list_base;
-    a.lists_per_query = pass.lists_per_query;
+    a.tile_stride = pass.tile_stride < 1 ? 1 : pass.tile_stride;
+    a.tile_max = pass.tile_max;
     a.k = k;
     a.slack = plan.slack;
     a.debug_no_candidates = getenv("MTR_MFMA_DEBUG") ? atoi(getenv("MTR_MFMA_DEBUG")) : 0;
@@ -531,38 +553,54 @@ hipError_t launch_score_mfma(const void* rows, int dtype, int64_t n, int ld, con
         return hipGetLastError();
     };
 #define MTR_MFMA_PICK(T)                                                                              \
+    if (a.tile_max != nullptr) switch (plan.tnq) {                                                    \
+        case 32: return launch(&score_topk_mfma_kernel<T, 256, 32, true>);                            \
+        case 64: return launch(&score_topk_mfma_kernel<T, 256, 64, true>);                            \
+        case 128: return launch(&score_topk_mfma_kernel<T, 256, 128, true>);                          \
+        default: return hipErrorInvalidValue;                                                         \
+    }                                                                                                 \
     switch (plan.tnq + (plan.cap == 256 ? 0 : 1)) {                                                   \
-        case 32: return launch(&score_topk_mfma_kernel<T, 256, 32>);                                  \
-        case 33: return launch(&score_topk_mfma_kernel<T, 512, 32>);                                  \
-        case 64: return launch(&score_topk_mfma_kernel<T, 256, 64>);                                  \
-        case 65: return launch(&score_topk_mfma_kernel<T, 512, 64>);                                  \
-        case 128: return launch(&score_topk_mfma_kernel<T, 256, 128>);                                \
-        default: return launch(&score_topk_mfma_kernel<T, 512, 128>);                                 \
+        case 32: return launch(&score_topk_mfma_kernel<T, 256, 32, false>);                           \
+        case 33: return launch(&score_topk_mfma_kernel<T, 512, 32, false>);                           \
+        case 64: return launch(&score_topk_mfma_kernel<T, 256, 64, false>);                           \
+        case 65: return launch(&score_topk_mfma_kernel<T, 512, 64, false>);                           \
+        case 128: return launch(&score_topk_mfma_kernel<T, 256, 128, false>);                         \
+        default: return launch(&score_topk_mfma_kernel<T, 512, 128, false>);                          \
     }
     if (dtype == 0) { MTR_MFMA_PICK(float) }
-    if (plan.tnq == 256) return launch(&score_topk_mfma_kernel<bf16_t, 512, 256>);
+    if (plan.tnq == 256 && a.tile_max == nullptr) return launch(&score_topk_mfma_kernel<bf16_t, 512, 256, false>);
     MTR_MFMA_PICK(bf16_t)
 #undef MTR_MFMA_PICK
 }
 
 namespace {
-__global__ void floor_from_sample_kernel(const float* kth_score, long long stride, int b, unsigned int* shared_floor,
-                                         int n_words) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= n_words) return;
-    unsigned int bits = 0;  // 0 = no floor known
-    if (q < b) {
-        const float s = kth_score[(long long)q * stride];
-        if (s > -__builtin_huge_valf()) bits = order_f32(s);
+// One wave per query: the k-th largest of its per-tile best scores.  Each of
+// those k tiles holds a row scoring at least that much, so no row below it can
+// be among the query's k best: it becomes the query's starting floor.
+template <int E>
+__global__ __launch_bounds__(64) void floor_from_tile_max_kernel(const unsigned int* tile_max, int n_tiles, int k,
+                                                                 unsigned int* shared_floor) {
+    const int q = blockIdx.x;
+    const int lane = threadIdx.x;
+    unsigned long long key[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int t = e * 64 + lane;
+        // the tile number makes equal scores distinct keys; 0 marks an empty slot
+        key[e] = t < n_tiles ? ((unsigned long long)tile_max[(size_t)q * n_tiles + t] << 32) | (unsigned int)(t + 1) : 0ull;
     }
-    shared_floor[q] = bits;
+    const unsigned long long cut = wave_kth_largest<E>(key, k);
+    if (lane == 0) shared_floor[q] = (unsigned int)(cut >> 32);  // 0 (fewer than k+1 tiles): no floor
 }
 }  // namespace
 
-hipError_t launch_floor_from_sample(const float* kth_score, long long stride, int b, unsigned int* shared_floor,
-                                    int n_words, hipStream_t stream) {
-    hipLaunchKernelGGL(floor_from_sample_kernel, dim3((n_words + 255) / 256), dim3(256), 0, stream, kth_score, stride, b,
-                       shared_floor, n_words);
+hipError_t launch_floor_from_tile_max(const unsigned int* tile_max, int n_tiles, int b, int k,
+                                      unsigned int* shared_floor, hipStream_t stream) {
+    if (n_tiles > kMaxSampleTiles) return hipErrorInvalidValue;
+    if (n_tiles <= 256)
+        hipLaunchKernelGGL(floor_from_tile_max_kernel<4>, dim3(b), dim3(64), 0, stream, tile_max, n_tiles, k, shared_floor);
+    else
+        hipLaunchKernelGGL(floor_from_tile_max_kernel<16>, dim3(b), dim3(64), 0, stream, tile_max, n_tiles, k, shared_floor);
     return hipGetLastError();
 }
 

@@ -361,13 +361,13 @@ def test_matrix_core_matches_scan(native):
 @pytest.mark.parametrize("store", ["bf16", "fp32"])
 @pytest.mark.parametrize("stride", [2, 5, 16])
 def test_sampled_two_launch_search_equals_single_launch(native, store, stride):
-    """Large shards are searched as two launches (every stride-th row tile
-    first, its k-th best scores as the floors of the rest).  Forced here on a
-    small shard: the result must be identical to the single launch, ties and a
-    ragged last tile included."""
+    """Large shards get a sampling launch first (every stride-th row tile; the
+    k-th largest per-tile best score becomes each query's starting floor).
+    Forced here on a small shard: the result must be identical to the single
+    launch, ties and a ragged, sampled last tile included."""
     import os
     rng = np.random.default_rng(500 + stride)
-    n, d, b, k = 128 * 67 + 45, 256, 37, 24
+    n, d, b, k = 128 * 300 + 45, 256, 37, 24   # 301 row tiles: strides up to 301 // (2 k) = 6 are honoured
     corpus = rng.standard_normal((n, d)).astype(np.float32)
     queries = rng.standard_normal((b, d)).astype(np.float32)
     # exact ties across sampled and other tiles, one of them in the ragged last tile
