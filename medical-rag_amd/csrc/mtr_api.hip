@@ -124,16 +124,16 @@ int check_index(const mtr_index* ix) {
 // flag set for the caller to read.
 // Smallest batch that goes to the matrix-core kernel; below it the HBM-bound
 // scan handles the batch in passes of up to four queries.  Measured hand-over
-// (1M rows): bf16 x 1024 -- scan 0.46 ms for two queries, 0.80 ms for four,
-// matrix cores (32-query tiles) 0.43 ms for three; fp32 x 768 -- scan 0.52 ms
-// for two, 0.80 ms for four, matrix cores (fp32 MFMA) 0.65 ms for three or four.
+// (1M rows): bf16 x 1024 -- scan 0.33 ms for one query, 0.46 ms for two,
+// matrix cores (32-query tiles) 0.40 ms for two to eight; fp32 x 768 -- scan
+// 0.50 ms for two, 0.80 ms for four, matrix cores (fp32 MFMA) 0.61 ms for three.
 int mfma_min_batch(int dtype) {
     static const int forced = [] {
         const char* e = getenv("MTR_MFMA_MIN_BATCH");
         return e ? atoi(e) : 0;
     }();
     if (forced > 0) return forced;
-    return 3;
+    return dtype == MTR_BF16 ? 2 : 3;
 }
 
 // Every how many row tiles one goes into the sampling launch (< 2: no sample).

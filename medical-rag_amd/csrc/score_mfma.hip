@@ -496,10 +496,11 @@ int plan_mfma(int dtype, int64_t n, int ld, int b, int k, int num_cus, MfmaPlan*
     plan->tm = tm;
     const long long n_tiles = (n + tm - 1) / tm;
     plan->n_tiles = n_tiles;
-    // Two workgroups per CU measured best for every four-wave tile: more, shorter
-    // row ranges cost more in top-k selection than they gain in bytes in flight.
-    // The eight-wave tile fills a CU with one workgroup.
-    long long per_cu = tm == 256 ? 1 : 2;
+    // Workgroups per CU (= row ranges x query tiles / CUs): more, shorter row
+    // ranges cost more in top-k selection than they gain in bytes in flight.
+    // Measured best: 3 for the 32-query tile (four fit), 2 for the 64- and
+    // 128-query tiles; the eight-wave tile fills a CU with one workgroup.
+    long long per_cu = tm == 256 ? 1 : plan->tnq == 32 ? 3 : 2;
     if (const char* e = getenv("MTR_MFMA_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
     long long ranges = (per_cu * num_cus + plan->n_qtiles - 1) / plan->n_qtiles;
     if (ranges > n_tiles) ranges = n_tiles;

@@ -188,7 +188,7 @@ def test_random_shapes(rag, store, n, d, b, k):
     if store == "bf16" and d < 256:
         # bf16 keeps 8 significant bits: |score error| <= 2^-9 * sum|p_i q_i| <= 2^-9 for unit
         # vectors (2^-8 when the queries are rounded too, as on the matrix-core path for
-        # b >= 3), which only averages down below 1e-3 once d is a few hundred.
+        # b >= 2), which only averages down below 1e-3 once d is a few hundred.
         tol = 2.0 ** -8
     check_topk(idx, score, s64, k, tol, exact_idx=False)
     if store == "fp32" and n > 10:
@@ -302,7 +302,7 @@ def test_full_size_properties(native):
 
 
 MFMA_SHAPES = [
-    # n, d, b, k   (rows that are a multiple of 128 bytes and b >= 3 take the matrix-core kernel;
+    # n, d, b, k   (rows that are a multiple of 128 bytes and b >= 2 (bf16) / 3 (fp32) take the matrix-core kernel;
     #               b <= 32 / <= 64 / more select its 32- / 64- / 128-query tiles, k <= 32 the small buffers)
     (5000, 512, 5, 10),
     (3000, 320, 31, 40),
@@ -348,8 +348,8 @@ def test_matrix_core_matches_scan(native):
     corpus = rng.standard_normal((n, d)).astype(np.float32)
     queries = rng.standard_normal((b, d)).astype(np.float32)
     shard = native.DeviceShard.from_host(corpus, store_dtype="bf16")
-    big_i, big_s = shard.search(queries, k=k)                       # b >= 3: matrix cores
-    parts = [shard.search(queries[i:i + 2], k=k) for i in range(0, b, 2)]  # b = 2: scan
+    big_i, big_s = shard.search(queries, k=k)                       # b >= 2: matrix cores
+    parts = [shard.search(queries[i:i + 1], k=k) for i in range(b)]  # b = 1: scan
     scan_i = np.concatenate([p[0] for p in parts]); scan_s = np.concatenate([p[1] for p in parts])
     stored = shard.read_rows().astype(np.float64)
     s64 = orc.normalize_rows(queries) @ stored.T   # exact scores of the STORED rows
