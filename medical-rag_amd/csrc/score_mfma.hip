@@ -45,21 +45,15 @@ namespace mtr {
 
 namespace {
 
-// Queries per tile are a template parameter TNQ, so that small batches do not
-// pay for 128 columns.  Tiles of 32 / 64 / 128 queries x 128 rows use four
-// waves: 128 (waves 2x2, each 64 rows x 64 queries = 2x2 MFMA tiles), 64 (waves
-// 2x2, each 64 x 32 = 2x1), 32 (waves 4x1, each 32 x 32).  Large batches take
-// 256 queries x 256 rows with eight waves (2x4, each 128 rows x 64 queries =
-// 4x2 MFMA tiles): per flop that tile moves half the bytes from L2 into LDS,
-// which is what bounds the 128-wide tile.  With only two stage buffers one
-// such workgroup per CU cannot keep enough loads in flight (measured 14.1 ms
-// against 9.7 ms for the 128-wide tile on 1M x 1024, 4096 queries), so it is
-// selected only by MTR_MFMA_TNQ=256 until it gets a deeper load ring.
+// Row tiles are 128 rows; queries per tile are a template parameter TNQ, so
+// that small batches do not pay for 128 columns.  Four waves per workgroup:
+// TNQ 128: waves 2x2, each 64 rows x 64 queries = 2x2 MFMA tiles; 64: waves 2x2,
+// each 64 x 32 = 2x1; 32: waves 4x1, each 32 x 32.
+constexpr int TM = 128;
+constexpr int kThreads = 256;
 constexpr int kStepBytes = 128;  // K bytes of a row per step: 64 bf16 or 32 fp32
-constexpr int tile_rows(int tnq) { return tnq == 256 ? 256 : 128; }
-constexpr int tile_threads(int tnq) { return tnq == 256 ? 512 : 256; }
-constexpr int stage_bytes(int tnq) { return (tile_rows(tnq) + tnq) * kStepBytes; }  // row tile then query tile
-constexpr int lds_bytes(int tnq) { return 2 * stage_bytes(tnq) + tnq * 12 + (tile_threads(tnq) / 64) * 1024; }
+constexpr int stage_bytes(int tnq) { return (TM + tnq) * kStepBytes; }  // row tile then query tile
+constexpr int lds_bytes(int tnq) { return 2 * stage_bytes(tnq) + tnq * 12 + (kThreads / 64) * 1024; }
 
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -232,12 +226,10 @@ __device__ __forceinline__ void compact_query(unsigned long long* buf, int c, in
 // per tile (a.tile_max).  A compile-time switch: as a run-time branch it made
 // the compiler copy all accumulators after every K step.
 template <typename T, int CAP, int TNQ, bool MAX_ONLY>
-__global__ __launch_bounds__(tile_threads(TNQ), 2) void score_topk_mfma_kernel(MfmaArgs a) {
+__global__ __launch_bounds__(kThreads, 2) void score_topk_mfma_kernel(MfmaArgs a) {
     constexpr int TN = TNQ;
-    constexpr int TM = tile_rows(TNQ);
-    constexpr int kThreads = tile_threads(TNQ);
     constexpr int WAVES = kThreads / 64;
-    constexpr int WN = TNQ == 32 ? 1 : TNQ == 256 ? 4 : 2;  // waves along the queries
+    constexpr int WN = TNQ == 32 ? 1 : 2;                   // waves along the queries
     constexpr int WM = WAVES / WN;                          // ... and along the rows
     constexpr int MT = TM / (32 * WM);           // MFMA tiles per wave along the rows
     constexpr int NT = TNQ / (32 * WN);          // ... and along the queries
@@ -486,10 +478,9 @@ int plan_mfma(int dtype, int64_t n, int ld, int b, int k, int num_cus, MfmaPlan*
     plan->tnq = b <= 32 ? 32 : b <= 64 ? 64 : 128;
     if (const char* e = getenv("MTR_MFMA_TNQ")) {
         const int t = atoi(e);
-        if (t == 32 || t == 64 || t == 128 || (t == 256 && dtype != 0)) plan->tnq = t;
+        if (t == 32 || t == 64 || t == 128) plan->tnq = t;
     }
-    const int tm = tile_rows(plan->tnq);
-    if (tm == 256) plan->cap = 512;
+    const int tm = TM;
     plan->slack = (plan->cap - tm - k) / 4;
     if (plan->slack > 64) plan->slack = 64;
     plan->n_qtiles = (b + plan->tnq - 1) / plan->tnq;
@@ -499,8 +490,8 @@ int plan_mfma(int dtype, int64_t n, int ld, int b, int k, int num_cus, MfmaPlan*
     // Workgroups per CU (= row ranges x query tiles / CUs): more, shorter row
     // ranges cost more in top-k selection than they gain in bytes in flight.
     // Measured best: 3 for the 32-query tile (four fit), 2 for the 64- and
-    // 128-query tiles; the eight-wave tile fills a CU with one workgroup.
-    long long per_cu = tm == 256 ? 1 : plan->tnq == 32 ? 3 : 2;
+    // 128-query tiles.
+    long long per_cu = plan->tnq == 32 ? 3 : 2;
     if (const char* e = getenv("MTR_MFMA_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
     long long ranges = (per_cu * num_cus + plan->n_qtiles - 1) / plan->n_qtiles;
     if (ranges > n_tiles) ranges = n_tiles;
@@ -550,7 +541,7 @@ hipError_t launch_score_mfma(const void* rows, int dtype, int64_t n, int ld, con
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kernel, dim3(plan.grid), dim3(tile_threads(plan.tnq)), plan.lds, stream, a);
+        hipLaunchKernelGGL(kernel, dim3(plan.grid), dim3(kThreads), plan.lds, stream, a);
         return hipGetLastError();
     };
 #define MTR_MFMA_PICK(T)                                                                              \
@@ -569,7 +560,6 @@ hipError_t launch_score_mfma(const void* rows, int dtype, int64_t n, int ld, con
         default: return launch(&score_topk_mfma_kernel<T, 512, 128, false>);                          \
     }
     if (dtype == 0) { MTR_MFMA_PICK(float) }
-    if (plan.tnq == 256 && a.tile_max == nullptr) return launch(&score_topk_mfma_kernel<bf16_t, 512, 256, false>);
     MTR_MFMA_PICK(bf16_t)
 #undef MTR_MFMA_PICK
 }
