@@ -212,6 +212,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     n_launch, scan_ms = shard.scan_time()
+    samples = sorted(shard.scan_samples())
     shard.profile(False)
     if world > 1:
         t = torch.tensor([elapsed], device=f"cuda:{local_rank}", dtype=torch.float64)
@@ -263,6 +264,10 @@ def main():
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "kernel": kernel, "kernel_avg_ms": scan_avg_ms,
                     "launches_per_step": passes, "algorithmic_bytes_per_launch": local_bytes}
+        for r in (roof,):  # spread of the per-launch HIP-event times behind kernel_avg_ms
+            if samples:
+                r["kernel_ms_p50"] = samples[len(samples) // 2]
+                r["kernel_ms_p95"] = samples[min(len(samples) - 1, int(0.95 * len(samples)))]
         res = {
             "metric": METRIC,
             "value": batch * args.steps / elapsed,

@@ -130,6 +130,9 @@ int mtr_index_read_rows(mtr_index_t* index, int64_t row_start, int64_t n_rows, f
  * events and returns their count and total milliseconds. */
 int mtr_index_profile(mtr_index_t* index, int32_t enable);
 int mtr_index_scan_time(mtr_index_t* index, int32_t* n_launches, double* total_ms);
+/* The same samples one by one: up to cap durations (milliseconds, in launch
+ * order) into out_ms, their full count into n_launches. */
+int mtr_index_scan_samples(mtr_index_t* index, float* out_ms, int32_t cap, int32_t* n_launches);
 
 void mtr_index_destroy(mtr_index_t* index);
 

@@ -39,6 +39,7 @@ SIGNATURES = {
     "mtr_index_read_rows": (_i32, [_vp, _i64, _i64, _vp]),
     "mtr_index_profile": (_i32, [_vp, _i32]),
     "mtr_index_scan_time": (_i32, [_vp, C.POINTER(_i32), C.POINTER(C.c_double)]),
+    "mtr_index_scan_samples": (_i32, [_vp, C.POINTER(C.c_float), _i32, C.POINTER(_i32)]),
     "mtr_index_destroy": (None, [_vp]),
     "mtr_last_error": (C.c_char_p, []),
     "mtr_version": (C.c_char_p, []),
@@ -232,6 +233,14 @@ class DeviceShard:
         n, ms = _i32(), C.c_double()
         check(lib().mtr_index_scan_time(self._h, C.byref(n), C.byref(ms)))
         return n.value, ms.value
+
+    def scan_samples(self):
+        """Milliseconds of every scoring launch since profile(True), in launch order."""
+        n = _i32()
+        check(lib().mtr_index_scan_samples(self._h, None, 0, C.byref(n)))
+        buf = (C.c_float * max(n.value, 1))()
+        check(lib().mtr_index_scan_samples(self._h, buf, n.value, C.byref(n)))
+        return [buf[i] for i in range(n.value)]
 
     def close(self):
         if self._h is not None and self._h.value:

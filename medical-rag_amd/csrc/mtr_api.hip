@@ -522,6 +522,20 @@ int mtr_index_scan_time(mtr_index_t* ix, int32_t* n_launches, double* total_ms) 
     return MTR_OK;
 }
 
+int mtr_index_scan_samples(mtr_index_t* ix, float* out_ms, int32_t cap, int32_t* n_launches) {
+    int rc = check_index(ix);
+    if (rc != MTR_OK) return rc;
+    if (cap < 0 || (cap > 0 && !out_ms)) return fail(MTR_ERR_INVALID, "out_ms is NULL or cap is negative");
+    std::lock_guard<std::mutex> lock(ix->mu);
+    DeviceGuard guard(ix->device);
+    for (size_t i = 0; i < ix->events_used && i < (size_t)cap; ++i) {
+        HIP_TRY(hipEventSynchronize(ix->events[i].second));
+        HIP_TRY(hipEventElapsedTime(&out_ms[i], ix->events[i].first, ix->events[i].second));
+    }
+    if (n_launches) *n_launches = (int32_t)ix->events_used;
+    return MTR_OK;
+}
+
 void mtr_index_destroy(mtr_index_t* ix) {
     if (!ix) return;
     {
