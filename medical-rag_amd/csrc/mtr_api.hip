@@ -97,6 +97,8 @@ struct mtr_index {
     DevBuf q_in;       // staging for host queries
     DevBuf cand_s, cand_i;
     DevBuf q_bf16;     // query tiles (storage type) for the matrix-core kernel
+    int64_t q_init_rows = 0;   // its rows [0, q_init_rows) have been written or zeroed at least once ...
+    int64_t q_data_rows = 0;   // ... and only rows [0, q_data_rows) of them can hold non-zero data
     DevBuf mfma_cand;  // its workgroups' candidate buffers
     DevBuf mfma_floor; // per-query floor shared by the row ranges
     DevBuf tile_max;   // the sampling launch's best score per (query, sampled tile)
@@ -178,16 +180,32 @@ int enqueue_mfma(mtr_index* ix, const mtr::MfmaPlan& plan, const void* dev_queri
         if (mtr::plan_mfma(ix->dtype, n_samp * plan.tm, ix->ld, b, k, ix->num_cus, &samp) != 0)
             return fail(MTR_ERR_INVALID, "internal: no launch shape for the sampling launch");
     }
-    const size_t qbytes = (size_t)plan.n_qtiles * plan.tnq * ix->ld * dtype_size(ix->dtype);
+    const size_t q_row_bytes = (size_t)ix->ld * dtype_size(ix->dtype);
+    const int64_t q_rows = (int64_t)plan.n_qtiles * plan.tnq;
+    const size_t qbytes = (size_t)q_rows * q_row_bytes;
+    const void* q_before = ix->q_bf16.p;
     if ((rc = ix->q_bf16.reserve(qbytes)) != MTR_OK) return rc;
+    if (ix->q_bf16.p != q_before) ix->q_init_rows = ix->q_data_rows = 0;
     if ((rc = ix->mfma_cand.reserve(plan.cand_bytes)) != MTR_OK) return rc;
     if ((rc = ix->cand_s.reserve((size_t)b * plan.n_ranges * k * 4)) != MTR_OK) return rc;
     if ((rc = ix->cand_i.reserve((size_t)b * plan.n_ranges * k * 4)) != MTR_OK) return rc;
     const int floor_words = plan.n_qtiles * plan.tnq;
     if ((rc = ix->mfma_floor.reserve((size_t)floor_words * 4)) != MTR_OK) return rc;
     if (stride >= 2 && (rc = ix->tile_max.reserve((size_t)floor_words * samp.n_tiles * 4)) != MTR_OK) return rc;
-    HIP_TRY(hipMemsetAsync(ix->mfma_floor.p, 0, (size_t)floor_words * 4, stream));
-    HIP_TRY(hipMemsetAsync(ix->q_bf16.p, 0, qbytes, stream));
+    // The sampling launch's floor kernel sets every real query's floor; otherwise they start from zero.
+    if (stride < 2) HIP_TRY(hipMemsetAsync(ix->mfma_floor.p, 0, (size_t)floor_words * 4, stream));
+    // Query rows past b must be zero.  The buffer keeps its contents between
+    // searches, so only rows never initialised, or holding an earlier, larger
+    // batch, are cleared: nothing in the steady state of equal batch sizes.
+    char* qbuf = static_cast<char*>(ix->q_bf16.p);
+    if (q_rows > ix->q_init_rows) {
+        HIP_TRY(hipMemsetAsync(qbuf + (size_t)ix->q_init_rows * q_row_bytes, 0,
+                               (size_t)(q_rows - ix->q_init_rows) * q_row_bytes, stream));
+        ix->q_init_rows = q_rows;
+    }
+    if (ix->q_data_rows > b)
+        HIP_TRY(hipMemsetAsync(qbuf + (size_t)b * q_row_bytes, 0, (size_t)(ix->q_data_rows - b) * q_row_bytes, stream));
+    ix->q_data_rows = b;
     HIP_TRY(mtr::launch_load_rows(dev_queries, q_dtype, b, ix->d, ix->q_bf16.p, ix->dtype, ix->ld,
                                   metric == MTR_COSINE ? 1 : 0, ix->flag, stream));
     hipEvent_t e0 = nullptr, e1 = nullptr;

@@ -392,6 +392,23 @@ def test_sampled_two_launch_search_equals_single_launch(native, store, stride):
     shard.close()
 
 
+@pytest.mark.parametrize("store", ["bf16", "fp32"])
+def test_batches_of_changing_size_on_one_shard(native, store):
+    """The shard keeps its query staging buffer between searches and clears
+    only what an earlier, larger batch left behind: shrinking, growing and
+    tile-width-changing batch sizes in a row must each match the oracle."""
+    rng = np.random.default_rng(61)
+    n, d, k = 3000, 256, 12
+    corpus = rng.standard_normal((n, d)).astype(np.float32)
+    shard = native.DeviceShard.from_host(corpus, store_dtype=store)
+    tol = 1e-6 if store == "fp32" else 1e-3
+    for b in (40, 5, 33, 130, 3, 64, 129, 2, 200):
+        queries = rng.standard_normal((b, d)).astype(np.float32)
+        idx, score = shard.search(queries, k=k)
+        check_topk(idx, score, orc.scores(queries, corpus), k, tol)
+    shard.close()
+
+
 def test_merge_reads_packed_gathered_buffer(native):
     """The exchange buffer layout of the multi-GPU path: every rank's ids and
     scores in one block, merged through strided views without copies."""
