@@ -409,6 +409,28 @@ def test_batches_of_changing_size_on_one_shard(native, store):
     shard.close()
 
 
+def test_repeated_searches_are_identical(native):
+    """Row ranges share floors through atomics, so which candidates a range keeps
+    depends on timing; the merged result must not.  Same search, ten times."""
+    import torch
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    n, d, b, k = 150_000, 256, 300, 50
+    rows = torch.randn((n, d), generator=gen, device="cuda")
+    queries = torch.randn((b, d), generator=gen, device="cuda")
+    shard = native.DeviceShard.alloc(n, d, store_dtype="bf16")
+    shard.load_device(0, rows)
+    first_i, first_s = (t.clone() for t in shard.search_device(queries, k=k))
+    for _ in range(9):
+        idx, score = shard.search_device(queries, k=k)
+        assert torch.equal(idx, first_i) and torch.equal(score, first_s)
+    # and the result is right: float64 re-scoring of the stored rows
+    stored = torch.from_numpy(shard.read_rows()).cuda().double()
+    qn = torch.nn.functional.normalize(queries.double(), dim=1)
+    want = (qn[:8] @ stored.T).topk(k, dim=1)
+    assert torch.equal(want.indices, first_i[:8]) or (want.values - first_s[:8].double()).abs().max() < 1e-3
+    shard.close()
+
+
 def test_merge_reads_packed_gathered_buffer(native):
     """The exchange buffer layout of the multi-GPU path: every rank's ids and
     scores in one block, merged through strided views without copies."""
