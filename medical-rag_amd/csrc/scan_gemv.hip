@@ -23,6 +23,10 @@
 //
 // Algorithmic bytes per launch: n * ld * sizeof(T) (each stored row byte is
 // read once); the query and candidate traffic is negligible beside it.
+#include <stdlib.h>
+
+#include <algorithm>
+
 #include "mtr_device.h"
 #include "wave_topk.h"
 
@@ -326,7 +330,15 @@ int plan_scan(int dtype, int64_t n, int d, int ld, int b, int k, int num_cus, Sc
     const long long ngroups = (n + rpg - 1) / rpg;
     const int kWaves = waves_per_group(qb);
     long long want = (ngroups + kWaves - 1) / kWaves;
-    const long long cap = (long long)num_cus * occ;
+    // One resident wave of workgroups for shards up to a few GB.  On larger
+    // shards up to four times as many, each still streaming about 20 MB: the
+    // finer grain evens out the end of the launch (10M x 1024 bf16: 2.977 ->
+    // 2.933 ms), while on 1M x 768 fp32 more workgroups only add list folding
+    // and merge work (0.468 -> 0.492 ms at six per CU).
+    long long cap = (long long)num_cus * occ;
+    const long long by_size = (long long)((double)n * ld * esize / 20.0e6);
+    cap = std::max(cap, std::min(by_size, 4LL * num_cus));
+    if (const char* e = getenv("MTR_SCAN_WG_PER_CU")) cap = atoi(e) > 0 ? (long long)num_cus * atoi(e) : cap;
     plan->grid = (int)(want < cap ? want : cap);
     if (plan->grid < 1) plan->grid = 1;
     return 0;
