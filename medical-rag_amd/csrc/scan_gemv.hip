@@ -17,9 +17,9 @@
 //   - Each lane accumulates R*QB partial dot products; a butterfly exchange
 //     (halve the values, double the lanes summed) leaves every (row, query)
 //     total on its own lane after about R*QB cross-lane moves.
-//   - Totals go to the wave's per-query top-k lists (wave_topk.h); the four
-//     waves of a workgroup merge their lists at the end and the workgroup
-//     writes one sorted candidate list per query.
+//   - Totals go to the wave's per-query top-k lists (wave_topk.h); the waves
+//     of a workgroup (16, or 8 with several queries) fold their lists pairwise
+//     at the end and the workgroup writes one sorted candidate list per query.
 //
 // Algorithmic bytes per launch: n * ld * sizeof(T) (each stored row byte is
 // read once); the query and candidate traffic is negligible beside it.
