@@ -1,28 +1,29 @@
 // Batched scoring on the matrix cores with the top-k selection fused in: a
-// tiled  rows x queries  bf16 contraction (v_mfma_f32_32x32x16_bf16) whose
-// score tiles never leave the registers.
+// tiled  rows x queries  contraction whose score tiles never leave the
+// registers -- v_mfma_f32_32x32x16_bf16 for bf16 shards, v_mfma_f32_32x32x2_f32
+// (exact fp32 products, blocked summation) for fp32 shards.
 //
 // This is the many-queries form of retrieve_top_index
 // (pipeline/utils/local_rag.py:76-78): all unique keyword vectors of a run
 // (pipeline/async_main.py:193-195) scored in one pass over the page matrix.
 //
-// Work split.  Queries are cut into tiles of 128, the stored rows into ranges;
-// one workgroup (4 waves) owns one (query tile, row range) pair and sweeps the
-// range in tiles of 128 rows.  Workgroups that share a query tile are placed on
-// one XCD (consecutive ids after the XCD remap), so that tile stays in that
-// XCD's L2 while every XCD streams the rows.
+// Work split.  Queries are cut into tiles of 32, 64 or 128 (by batch size), the
+// stored rows into ranges; one workgroup (4 waves) owns one (query tile, row
+// range) pair and sweeps the range in tiles of 128 rows.  Workgroups that share
+// a query tile are placed on one XCD (consecutive ids after the XCD remap), so
+// that tile stays in that XCD's L2 while every XCD streams the rows.
 //
-// Per 128x128 tile.  K runs over the row width in steps of 64: both operands
-// are K-contiguous (scores = rows . queries^T), so the row tile and the query
-// tile are staged with 16-byte direct-to-LDS loads into two buffers (the next
+// Per tile.  K runs over the row width in steps of 128 bytes: both operands are
+// K-contiguous (scores = rows . queries^T), so the row tile and the query tile
+// are staged with 16-byte direct-to-LDS loads into two buffers (the next
 // step's loads are issued before this step's MFMAs; one barrier per step).
 // The LDS image is 128-byte rows whose 16-byte chunks are XOR-swizzled with
 // the row number -- applied on the global source address, since a
 // direct-to-LDS load writes lane-linear -- which makes the ds_read_b128
-// fragment reads conflict-free.  Each wave computes a 64x64 sub-tile as 2x2
-// MFMA tiles with the rows as the A operand: the accumulator then holds ONE
-// query per lane (column = lane & 31) and 16 rows per register set, so the
-// per-query threshold test is one compare per lane.
+// fragment reads conflict-free.  Each wave computes its sub-tile as 32x32 MFMA
+// tiles with the rows as the A operand: the accumulator then holds ONE query
+// per lane (column = lane & 31) and 16 rows per register set, so the per-query
+// threshold test is one compare per lane.
 //
 // Fused top-k.  Each query keeps in LDS the score of its current k-th best
 // (the floor) and a count; scores above the floor are appended, as packed
@@ -30,11 +31,13 @@
 // global memory (L2-resident).  When a query's buffer could overflow on the
 // next tile, one wave re-selects its k best with a radix walk, which also
 // raises the floor.  Rows arrive in increasing order, so "strictly above the
-// floor" never drops a row that would win a tie.  At the end every query's k
-// best are written as one candidate list per row range; merge_topk.hip merges
-// the ranges.
+// floor" never drops a row that would win a tie.  A second, non-strict floor
+// per query is shared by all row ranges: it starts from a sampling launch
+// (MAX_ONLY below) on large shards and rises as ranges publish their own
+// floors.  At the end every query's k best are written as one candidate list
+// per row range; merge_topk.hip merges the ranges.
 //
-// Algorithmic work per launch: 2 * B * n * d flops (bf16 MFMA, fp32 accumulate).
+// Algorithmic work per launch: 2 * B * n * d flops (fp32 accumulate).
 #include <stdio.h>
 #include <stdlib.h>
 
