@@ -6,11 +6,13 @@
 // to merge the per-GPU lists.  The reference's counterpart is the single
 // np.argmax at pipeline/utils/local_rag.py:78.
 //
-// One workgroup per query.  Each wave streams a strided slice of the
-// candidates through its own top-k list (wave_topk.h), then wave 0 folds the
-// other waves' lists into its own and writes the result.  Every input list is
-// sorted (both producers write sorted lists), which the kernel uses to find a
-// floor for the k-th best from the list heads before touching the rest.
+// One workgroup per query, two kernels.  merge_select_kernel (32-bit local row
+// ids, k <= 256: the per-workgroup and per-range lists of one shard) selects
+// the k-th largest packed key of each wave's slice with a radix walk and folds
+// the survivors; it does not need sorted input.  merge_topk_kernel (64-bit ids
+// or larger k: the per-GPU lists after the all-gather) streams the candidates
+// through per-wave top-k lists (wave_topk.h); its producers write sorted lists,
+// which it uses to bound the k-th best from the list heads first.
 #include "mtr_device.h"
 #include "wave_select.h"
 #include "wave_topk.h"
