@@ -1,6 +1,7 @@
 // C ABI of the retrieval library (declared in include/medtutor_retrieval.h):
 // shard handles, the row loader, search and candidate merge.  Host-side only;
-// the kernels are in scan_gemv.hip, merge_topk.hip and load_rows.hip.
+// the kernels are in scan_gemv.hip (single queries), score_mfma.hip (batches),
+// merge_topk.hip, load_rows.hip and pool_normalize.hip.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
