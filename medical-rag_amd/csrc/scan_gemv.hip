@@ -17,8 +17,8 @@
 //   - Each lane accumulates R*QB partial dot products; a butterfly exchange
 //     (halve the values, double the lanes summed) leaves every (row, query)
 //     total on its own lane after about R*QB cross-lane moves.
-//   - Totals go to the wave's per-query top-k lists (wave_topk.h); the waves
-//     of a workgroup (16, or 8 with several queries) fold their lists pairwise
+//   - Totals go to the wave's per-query top-k lists (wave_topk.h); the eight
+//     waves of a workgroup fold their lists pairwise
 //     at the end and the workgroup writes one sorted candidate list per query.
 //
 // Algorithmic bytes per launch: n * ld * sizeof(T) (each stored row byte is
@@ -34,10 +34,11 @@ namespace mtr {
 
 namespace {
 
-// Waves per workgroup: one 16-wave workgroup per CU when a single query leaves
-// room for 4 waves per SIMD (128 registers), 8-wave workgroups otherwise.  Large
-// workgroups keep the number of candidate lists (one per workgroup) small.
-constexpr int waves_per_group(int qb) { return qb == 1 ? 16 : 8; }
+// Waves per workgroup.  Eight waves, with ONE workgroup per CU for a single
+// query, read fastest: a bare read loop of this access pattern peaks there too
+// (7.17 TB/s against 7.08 with sixteen waves, profiles/micro/read_patterns.hip),
+// and few workgroups keep the number of candidate lists (one each) small.
+constexpr int waves_per_group(int) { return 8; }
 // Rows per wave group: 8 for one or two queries, 4 beyond (register budget).
 constexpr int rows_per_group(int qb) { return qb <= 2 ? 8 : 4; }
 
@@ -330,14 +331,11 @@ int plan_scan(int dtype, int64_t n, int d, int ld, int b, int k, int num_cus, Sc
     const long long ngroups = (n + rpg - 1) / rpg;
     const int kWaves = waves_per_group(qb);
     long long want = (ngroups + kWaves - 1) / kWaves;
-    // One resident wave of workgroups for shards up to a few GB.  On larger
-    // shards up to four times as many, each still streaming about 20 MB: the
-    // finer grain evens out the end of the launch (10M x 1024 bf16: 2.977 ->
-    // 2.933 ms), while on 1M x 768 fp32 more workgroups only add list folding
-    // and merge work (0.468 -> 0.492 ms at six per CU).
-    long long cap = (long long)num_cus * occ;
-    const long long by_size = (long long)((double)n * ld * esize / 20.0e6);
-    cap = std::max(cap, std::min(by_size, 4LL * num_cus));
+    // Single query: one workgroup per CU measured best at every shard size (10M x
+    // 1024 bf16: 2.914 ms against 2.93-2.98 ms with 2-8 per CU; 1M x 768 fp32:
+    // 0.457 against 0.464 ms with two).  Several queries per pass need the
+    // occupancy to hide their longer dependent chains.
+    long long cap = (long long)num_cus * (qb == 1 ? 1 : occ);
     if (const char* e = getenv("MTR_SCAN_WG_PER_CU")) cap = atoi(e) > 0 ? (long long)num_cus * atoi(e) : cap;
     plan->grid = (int)(want < cap ? want : cap);
     if (plan->grid < 1) plan->grid = 1;
