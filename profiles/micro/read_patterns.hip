@@ -34,8 +34,9 @@ __global__ void rows_kernel(const char* __restrict__ src, long long n_rows, int 
 
 template <int R, int POLICY>
 void run(const char* buf, long long n_rows, int row_bytes, unsigned int* out, int cus, hipEvent_t e0, hipEvent_t e1) {
-    for (int waves : {8, 16})
+    for (int waves : {2, 4, 8, 16})
         for (int per_cu : {1, 2, 4, 8}) {
+            if (waves * per_cu > 32) continue;
             float sum = 0.f;
             const int reps = 6;
             for (int r = 0; r < reps + 1; ++r) {
@@ -67,6 +68,7 @@ int main() {
     hipDeviceProp_t prop;
     (void)hipGetDeviceProperties(&prop, 0);
     const int cus = prop.multiProcessorCount;
+    run<2, 1>(buf, n_rows, row_bytes, out, cus, e0, e1);
     run<4, 1>(buf, n_rows, row_bytes, out, cus, e0, e1);
     run<8, 1>(buf, n_rows, row_bytes, out, cus, e0, e1);
     run<16, 1>(buf, n_rows, row_bytes, out, cus, e0, e1);
