@@ -431,6 +431,37 @@ def test_repeated_searches_are_identical(native):
     shard.close()
 
 
+def test_concurrent_calls_on_one_handle(native):
+    """ctypes drops the GIL during a call, so threads really do enter the
+    library together; calls on one handle are serialised inside it and every
+    thread must get its own right answer (host-buffer entry point)."""
+    import threading
+    rng = np.random.default_rng(77)
+    n, d, k = 20000, 128, 8
+    corpus = rng.standard_normal((n, d)).astype(np.float32)
+    shard = native.DeviceShard.from_host(corpus, store_dtype="fp32")
+    batches = [rng.standard_normal((b, d)).astype(np.float32) for b in (1, 2, 5, 40, 1, 3, 70, 9)]
+    want = [orc.search(q, corpus, k) for q in batches]
+    errors = []
+
+    def worker(i):
+        try:
+            for _ in range(5):
+                idx, score = shard.search(batches[i], k=k)
+                if not (idx == want[i][0]).all() or np.abs(score - want[i][1]).max() > 1e-6:
+                    errors.append(i)
+        except Exception as exc:  # noqa: BLE001 -- reported below
+            errors.append((i, repr(exc)))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(len(batches))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    shard.close()
+
+
 def test_merge_reads_packed_gathered_buffer(native):
     """The exchange buffer layout of the multi-GPU path: every rank's ids and
     scores in one block, merged through strided views without copies."""
