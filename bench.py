@@ -152,6 +152,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-exchange", action="store_true",
                     help="initialise the process group and run the all-gather + merge even with one rank")
+    ap.add_argument("--pipeline-depth", type=int, default=-1,
+                    help="multi-GPU runs: searches whose exchange may still be in flight when the next scan starts "
+                         "(0: every search waits for its own exchange on the main stream; default: 2 from four "
+                         "ranks, where the all-gather takes long enough to be worth hiding, else 0)")
     args = ap.parse_args()
 
     import torch
@@ -194,11 +198,33 @@ def main():
     t_build = time.perf_counter() - t_build
     index = ShardedIndex(shard, always_exchange=args.force_exchange)
 
-    def step():
-        return index.search_device(queries, k=k, metric="cosine")
+    # Steps are independent searches.  With several ranks the all-gather and the
+    # final merge of a search run on a side stream while the next search's scan
+    # starts (a serving loop would do the same); every result is waited for
+    # before the clock stops.
+    exchanging = world > 1 or args.force_exchange
+    depth = args.pipeline_depth if args.pipeline_depth >= 0 else (2 if world >= 4 else 0)
+    if not exchanging:
+        depth = 0
+    pending = []
 
+    def step():
+        if depth <= 0:
+            return index.search_device(queries, k=k, metric="cosine")
+        pending.append(index.search_device_async(queries, k=k, metric="cosine", depth=depth))
+        if len(pending) > depth - 1:
+            return pending.pop(0).result()
+        return None
+
+    def drain(last):
+        while pending:
+            last = pending.pop(0).result()
+        return last
+
+    out = None
     for _ in range(args.warmup):
-        out = step()
+        out = step() or out
+    out = drain(out)
     torch.cuda.synchronize()
     shard.profile(True)
     if world > 1:
@@ -206,7 +232,8 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = step()
+        out = step() or out
+    out = drain(out)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -283,7 +310,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": w["name"], "rows": rows, "dim": dim, "batch": batch, "k": k,
                        "rows_per_gpu": hi - lo,
-                       "parallelism": f"row-shard x{world}" + (" + RCCL all-gather + k-way merge" if world > 1 else "")},
+                       "parallelism": f"row-shard x{world}" + (" + RCCL all-gather + k-way merge" if world > 1 else ""),
+                       "exchange_pipeline_depth": depth},
             "roofline": roof,
             "needles_found": bool(needle_ok),
             "build_s": t_build,

@@ -69,6 +69,22 @@ def exchange(mine: CandidateBlock, everyone: CandidateBlock, group=None):
         dist.all_gather_into_tensor(everyone.buf, mine.buf, group=group)
 
 
+class PendingSearch:
+    """A search whose exchange and final merge run on the index's side stream.
+    result() makes torch's current stream wait for them and returns the
+    (ids, scores) tensors; they stay valid until `depth` later searches of the
+    same shape have been started on the same index."""
+
+    def __init__(self, ids, scores, done):
+        self._ids, self._scores, self._done = ids, scores, done
+
+    def result(self):
+        import torch
+        if self._done is not None:
+            torch.cuda.current_stream(self._ids.device).wait_event(self._done)
+        return self._ids, self._scores
+
+
 class ShardedIndex:
     """This rank's shard plus the process group it searches with."""
 
@@ -79,6 +95,8 @@ class ShardedIndex:
         # rehearsal of the multi-GPU path on one GPU).
         self.always_exchange = always_exchange
         self._bufs = {}
+        self._rings = {}
+        self._side = None
 
     @property
     def world_size(self):
@@ -111,3 +129,46 @@ class ShardedIndex:
         self.shard.search_device(queries, k=k, metric=metric, out=(mine.ids[0], mine.scores[0]))
         exchange(mine, everyone, self.group)
         return _native.merge_topk_device(everyone.ids, everyone.scores, k, out=(out_i, out_s))
+
+    def search_device_async(self, queries, k: int = 10, metric: str = "cosine", depth: int = 2):
+        """Throughput form for streams of independent searches.  The local search is
+        enqueued on torch's current stream; the all-gather and the final merge
+        go to a side stream, so the next search's scan overlaps with this one's
+        exchange.  Returns a PendingSearch.  `depth` sets of buffers are cycled:
+        at most `depth` searches of one shape may be pending."""
+        import torch
+        from . import _native
+        if queries.dim() == 1:
+            queries = queries[None, :]
+        b = queries.shape[0]
+        device = queries.device
+        if self.world_size == 1 and not self.always_exchange:
+            ids, scores = self.search_device(queries, k=k, metric=metric)
+            return PendingSearch(ids, scores, None)
+        key = (b, k, str(device), depth)
+        ring = self._rings.get(key)
+        if ring is None:
+            ring = {"next": 0, "slots": [
+                {"mine": CandidateBlock(b, k, device), "everyone": CandidateBlock(b, k, device, n_blocks=self.world_size),
+                 "ids": torch.empty((b, k), dtype=torch.int64, device=device),
+                 "scores": torch.empty((b, k), dtype=torch.float32, device=device),
+                 "local_done": torch.cuda.Event(), "done": None} for _ in range(depth)]}
+            self._rings[key] = ring
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=device)
+        slot = ring["slots"][ring["next"]]
+        ring["next"] = (ring["next"] + 1) % depth
+        main = torch.cuda.current_stream(device)
+        if slot["done"] is not None:
+            main.wait_event(slot["done"])   # the slot's previous exchange has read `mine` and written the outputs
+        mine, everyone = slot["mine"], slot["everyone"]
+        self.shard.search_device(queries, k=k, metric=metric, out=(mine.ids[0], mine.scores[0]))
+        slot["local_done"].record(main)
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(slot["local_done"])
+            exchange(mine, everyone, self.group)
+            _native.merge_topk_device(everyone.ids, everyone.scores, k, out=(slot["ids"], slot["scores"]))
+            done = torch.cuda.Event()
+            done.record(self._side)
+        slot["done"] = done
+        return PendingSearch(slot["ids"], slot["scores"], done)

@@ -462,6 +462,40 @@ def test_concurrent_calls_on_one_handle(native):
     shard.close()
 
 
+def test_async_sharded_search_matches_sync(native):
+    """The pipelined form of the row-sharded search (exchange + final merge on a
+    side stream) on a one-rank RCCL group: a stream of searches must give what
+    the synchronous form gives, whatever the order of result() calls."""
+    import torch
+    import torch.distributed as dist
+    from medical_rag_amd.sharded import ShardedIndex
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29577", rank=0, world_size=1,
+                                device_id=torch.device("cuda:0"))
+    try:
+        rng = np.random.default_rng(3)
+        n, d, k = 30000, 256, 10
+        corpus = rng.standard_normal((n, d)).astype(np.float32)
+        shard = native.DeviceShard.from_host(corpus, store_dtype="fp32", row_offset=1000)
+        index = ShardedIndex(shard, always_exchange=True)
+        batches = [torch.from_numpy(rng.standard_normal((b, d)).astype(np.float32)).cuda() for b in (1, 1, 4, 1, 4, 4, 1, 1)]
+        want = [tuple(t.clone() for t in index.search_device(q, k=k)) for q in batches]
+        pending = [index.search_device_async(q, k=k, depth=2) for q in batches[:2]]
+        got = []
+        for q in batches[2:]:
+            got.append(tuple(t.clone() for t in pending.pop(0).result()))
+            pending.append(index.search_device_async(q, k=k, depth=2))
+        while pending:
+            got.append(tuple(t.clone() for t in pending.pop(0).result()))
+        torch.cuda.synchronize()
+        for (wi, ws), (gi, gs) in zip(want, got):
+            assert torch.equal(wi, gi) and torch.equal(ws, gs)
+        assert int(want[0][0].min()) >= 1000   # global ids carry the shard's row offset
+        shard.close()
+    finally:
+        dist.destroy_process_group()
+
+
 def test_merge_reads_packed_gathered_buffer(native):
     """The exchange buffer layout of the multi-GPU path: every rank's ids and
     scores in one block, merged through strided views without copies."""
