@@ -229,7 +229,11 @@ def _encoder_for(model_name: str, device: str):
 
 def pool_and_normalize(last_hidden_state, attention_mask):
     """Masked mean over tokens then L2 normalisation, the arithmetic of
-    pipeline/utils/local_rag.py:58-65 (torch tensors in, (B, d) tensor out)."""
+    pipeline/utils/local_rag.py:58-65 (torch tensors in, (B, d) tensor out).
+    It runs where the encoder ran: as one HIP kernel for GPU tensors, as the
+    reference's torch expression when the caller keeps the encoder on the CPU
+    (the reference's default embedding_model_device).  Scoring and top-k have
+    no such choice: they only exist on the GPU."""
     import torch
     if last_hidden_state.is_cuda:
         # one fused HIP kernel instead of five elementwise/reduction launches
