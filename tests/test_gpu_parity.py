@@ -214,6 +214,47 @@ def test_inner_product_metric(rag):
 
 
 @pytest.mark.parametrize("store", ["fp32", "bf16"])
+def test_integer_data_is_exact_with_many_ties(native, store):
+    """Small integer vectors under the inner-product metric: every product and
+    every partial sum is exact in fp32 and bf16, so ids AND scores must equal
+    the oracle bit for bit, and ties are everywhere (scores are small integers).
+    Random shapes across both kernels, all tile widths, k below and above n."""
+    rng = np.random.default_rng(2024)
+    widths = [1, 7, 33, 64, 100, 128, 192, 256, 320]
+    for case in range(60):
+        n = int(rng.integers(1, 4000))
+        d = int(rng.choice(widths))
+        b = int(rng.choice([1, 2, 3, 5, 31, 32, 33, 64, 65, 129, 140]))
+        k = int(rng.choice([1, 2, 10, 33, 100, 256, 300]))
+        corpus = rng.integers(-3, 4, size=(n, d)).astype(np.float32)
+        queries = rng.integers(-3, 4, size=(b, d)).astype(np.float32)
+        shard = native.DeviceShard.from_host(corpus, store_dtype=store, normalize=False)
+        idx, score = shard.search(queries, k=k, metric="ip")
+        want_i, want_s = orc.search(queries, corpus, k, metric="ip")
+        assert (idx == want_i).all(), (case, n, d, b, k)
+        assert (score == want_s.astype(np.float32)).all(), (case, n, d, b, k)
+        shard.close()
+    # one large tie-heavy case through the sampling launch (forced: the shard is below its size threshold)
+    import os
+    n, d, b, k = 200_000, 128, 40, 50
+    corpus = rng.integers(-2, 3, size=(n, d)).astype(np.float32)
+    queries = rng.integers(-2, 3, size=(b, d)).astype(np.float32)
+    shard = native.DeviceShard.from_host(corpus, store_dtype=store, normalize=False)
+    old = os.environ.get("MTR_MFMA_SAMPLE_STRIDE")
+    try:
+        os.environ["MTR_MFMA_SAMPLE_STRIDE"] = "12"
+        idx, score = shard.search(queries, k=k, metric="ip")
+    finally:
+        if old is None:
+            os.environ.pop("MTR_MFMA_SAMPLE_STRIDE", None)
+        else:
+            os.environ["MTR_MFMA_SAMPLE_STRIDE"] = old
+    want_i, want_s = orc.search(queries, corpus, k, metric="ip")
+    assert (idx == want_i).all() and (score == want_s.astype(np.float32)).all()
+    shard.close()
+
+
+@pytest.mark.parametrize("store", ["fp32", "bf16"])
 def test_stored_rows_are_normalised(rag, store):
     rng = np.random.default_rng(9)
     corpus = (rng.standard_normal((300, 130)) * 5).astype(np.float32)
