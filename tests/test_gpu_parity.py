@@ -268,6 +268,31 @@ def test_stored_rows_are_normalised(rag, store):
     index.close()
 
 
+@pytest.mark.parametrize("store", ["fp32", "bf16"])
+def test_sharded_merge_is_exact_on_integer_data(native, store):
+    """Uneven shards (one of a single row, one shorter than k) of tie-heavy
+    integer data, searched shard by shard and merged on the device: ids and
+    scores equal the unsharded oracle bit for bit, for small and large batches."""
+    import torch
+    rng = np.random.default_rng(808)
+    n, d = 9000, 128
+    corpus = rng.integers(-2, 3, size=(n, d)).astype(np.float32)
+    bounds = [0, 1, 8, 2500, 2501, 7000, n]
+    shards = [native.DeviceShard.from_host(corpus[lo:hi], store_dtype=store, normalize=False, row_offset=lo)
+              for lo, hi in zip(bounds[:-1], bounds[1:])]
+    for b, k in ((1, 10), (3, 10), (40, 25), (130, 7)):
+        queries = rng.integers(-2, 3, size=(b, d)).astype(np.float32)
+        q = torch.from_numpy(queries).cuda()
+        parts = [sh.search_device(q, k=k, metric="ip") for sh in shards]
+        gi, gs = native.merge_topk_device(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]), k)
+        torch.cuda.synchronize()
+        want_i, want_s = orc.search(queries, corpus, k, metric="ip")
+        assert (gi.cpu().numpy() == want_i).all(), (b, k)
+        assert (gs.cpu().numpy() == want_s.astype(np.float32)).all(), (b, k)
+    for sh in shards:
+        sh.close()
+
+
 def test_device_search_and_merge(native):
     import torch
     rng = np.random.default_rng(21)
