@@ -225,6 +225,113 @@ __device__ __forceinline__ void compact_query(unsigned long long* buf, int c, in
     finish_select<E>(buf, key, k, slack, floor_lds, cnt_lds, q, lane, shared_floor_q, hist);
 }
 
+// ---- pieces of the fused top-k shared by the tile shapes ---------------------
+
+// One 32 x 32 MFMA tile of finished scores (one query per lane column, 16 rows
+// per lane: row0 + (r & 3) + 8 * (r >> 2) for register r): appends what is
+// above the query's threshold to its candidate buffer and clears the tile.
+template <int CAP>
+__device__ __forceinline__ void append_above(f32x16& tile, float thr, int ql, long long row0, bool last_tile,
+                                             const MfmaArgs& a, int* cnt_lds, unsigned long long* my_buf) {
+    float mx = tile[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, tile[r]);
+    if (__any(mx > thr)) {
+        unsigned int pass = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pass |= (tile[r] > thr) ? (1u << r) : 0u;
+        if (last_tile) {  // only the last tile of the matrix can hold rows past its end
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (row0 + (r & 3) + 8 * (r >> 2) >= a.n) pass &= ~(1u << r);
+        }
+        // One LDS atomic per lane reserves all its slots at once (a
+        // returning atomic per element would serialise on LDS latency).
+        int slot = 0;
+        if (pass) {
+            const int np = __popc(pass);
+            slot = atomicAdd(&cnt_lds[ql], np);
+            if (a.debug_no_candidates & 4) atomicAdd(a.debug_counters, (unsigned long long)np);
+        }
+        // Registers any lane wants to store, as a wave-uniform mask: the
+        // sixteen tests below are then scalar branches.  (Letting every
+        // lane walk its own passing rows instead, with a select tree to
+        // fetch element r, measured 5-15 % slower at every batch size.)
+        unsigned int any_r = pass;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) any_r |= __shfl_xor(any_r, off, 64);
+        any_r = __builtin_amdgcn_readfirstlane(any_r);
+        unsigned long long* dst = my_buf + (size_t)ql * CAP;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (any_r & (1u << r)) {
+                if (pass & (1u << r)) {
+                    if (a.debug_no_candidates & 2) slot &= CAP - 1;
+                    if (slot < CAP) dst[slot] = pack_key(tile[r], (int)(row0 + (r & 3) + 8 * (r >> 2)));
+                    ++slot;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tile[r] = 0.f;
+}
+
+// The calling wave looks after queries [q0, q0 + nq), nq <= 64: re-selects any
+// whose buffer could overflow on the next tile (a tile adds at most tile_rows).
+template <int CAP>
+__device__ __forceinline__ void reselect_where_full(int q0, int nq, int tile_rows, int lane, const MfmaArgs& a,
+                                                    float* floor_lds, int* cnt_lds, unsigned long long* my_buf,
+                                                    unsigned int* shared_floor, unsigned int* hist_lds) {
+    constexpr int E = CAP / 64;
+    const int c = cnt_lds[q0 + (lane % nq)];
+    unsigned long long need = __ballot(lane < nq && c + tile_rows > CAP);  // k + slack + tile_rows <= CAP by plan
+    if (a.debug_no_candidates & 2) need = 0;
+    if ((a.debug_no_candidates & 4) && lane == 0 && need) atomicAdd(a.debug_counters + 1, (unsigned long long)__popcll(need));
+    while (need) {
+        const int j = __ffsll((long long)need) - 1;
+        need &= need - 1;
+        const int q = q0 + j;
+        const int cq = __builtin_amdgcn_readfirstlane(cnt_lds[q]);
+        compact_query<E>(my_buf + (size_t)q * CAP, cq, a.k, a.slack, floor_lds, cnt_lds, q, lane, shared_floor + q, hist_lds);
+    }
+}
+
+// Final selection of queries [q0, q0 + nq) of query tile base qt_base and one
+// candidate list per (query, range).
+template <int CAP>
+__device__ __forceinline__ void write_range_lists(int q0, int nq, int qt_base, int range, int lane, const MfmaArgs& a,
+                                                  float* floor_lds, int* cnt_lds, unsigned long long* my_buf,
+                                                  unsigned int* shared_floor, unsigned int* hist_lds) {
+    constexpr int E = CAP / 64;
+    for (int j = 0; j < nq; ++j) {
+        const int q = q0 + j;
+        const int qg = qt_base + q;
+        if (qg >= a.b) continue;  // wave-uniform
+        int cq = __builtin_amdgcn_readfirstlane(cnt_lds[q]);
+        unsigned long long* buf = my_buf + (size_t)q * CAP;
+        if (cq > a.k) {
+            compact_query<E>(buf, cq, a.k, 0, floor_lds, cnt_lds, q, lane, shared_floor + q, hist_lds);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            cq = __builtin_amdgcn_readfirstlane(cnt_lds[q]);
+        }
+        float* os = a.out_s + ((size_t)qg * a.n_ranges + range) * a.k;
+        int* oi = a.out_i + ((size_t)qg * a.n_ranges + range) * a.k;
+        for (int i = lane; i < a.k; i += 64) {
+            if (i < cq) {
+                const unsigned long long key = buf[i];
+                os[i] = key_score(key);
+                oi[i] = key_row(key);
+            } else {
+                os[i] = -__builtin_huge_valf();
+                oi[i] = -1;
+            }
+        }
+    }
+}
+
 // MAX_ONLY: the sampling form, which keeps nothing but each query's best score
 // per tile (a.tile_max).  A compile-time switch: as a run-time branch it made
 // the compiler copy all accumulators after every K step.
@@ -241,7 +348,6 @@ __global__ __launch_bounds__(kThreads, 2) void score_topk_mfma_kernel(MfmaArgs a
     constexpr int kStageBytes = stage_bytes(TNQ);
     constexpr int ROW_AUX = 0;  // default cache policy for the row tiles (non-temporal measured 13-28 % slower)
     constexpr int BK = kStepBytes / (int)sizeof(T);
-    constexpr int E = CAP / 64;
     static_assert((CAP & (CAP - 1)) == 0, "CAP must be a power of two");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const stage0 = smem;
@@ -351,52 +457,8 @@ __global__ __launch_bounds__(kThreads, 2) void score_topk_mfma_kernel(MfmaArgs a
                 // v > (largest float below sh); a NaN from sh = -inf loses the fmaxf.
                 const float thr = fmaxf(floor_lds[ql], unorder_f32(order_f32(shared_lds[ql]) - 1u));
 #pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    float mx = acc[m][n][0];
-#pragma unroll
-                    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[m][n][r]);
-                    if (__any(mx > thr)) {
-                        const long long row0 = row_base + m * 32;
-                        unsigned int pass = 0;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) pass |= (acc[m][n][r] > thr) ? (1u << r) : 0u;
-                        if (last_tile) {  // only the last tile of the matrix can hold rows past its end
-#pragma unroll
-                            for (int r = 0; r < 16; ++r)
-                                if (row0 + (r & 3) + 8 * (r >> 2) >= a.n) pass &= ~(1u << r);
-                        }
-                        // One LDS atomic per lane reserves all its slots at once (a
-                        // returning atomic per element would serialise on LDS latency).
-                        int slot = 0;
-                        if (pass) {
-                            const int np = __popc(pass);
-                            slot = atomicAdd(&cnt_lds[ql], np);
-                            if (a.debug_no_candidates & 4) atomicAdd(a.debug_counters, (unsigned long long)np);
-                        }
-                        // Registers any lane wants to store, as a wave-uniform mask: the
-                        // sixteen tests below are then scalar branches.  (Letting every
-                        // lane walk its own passing rows instead, with a select tree to
-                        // fetch element r, measured 5-15 % slower at every batch size.)
-                        unsigned int any_r = pass;
-#pragma unroll
-                        for (int off = 32; off >= 1; off >>= 1) any_r |= __shfl_xor(any_r, off, 64);
-                        any_r = __builtin_amdgcn_readfirstlane(any_r);
-                        unsigned long long* dst = my_buf + (size_t)ql * CAP;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            if (any_r & (1u << r)) {
-                                if (pass & (1u << r)) {
-                                    if (a.debug_no_candidates & 2) slot &= CAP - 1;
-                                    if (slot < CAP)
-                                        dst[slot] = pack_key(acc[m][n][r], (int)(row0 + (r & 3) + 8 * (r >> 2)));
-                                    ++slot;
-                                }
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-                }
+                for (int m = 0; m < MT; ++m)
+                    append_above<CAP>(acc[m][n], thr, ql, row_base + m * 32, last_tile, a, cnt_lds, my_buf);
             }
         }
         __syncthreads();
@@ -414,18 +476,7 @@ __global__ __launch_bounds__(kThreads, 2) void score_topk_mfma_kernel(MfmaArgs a
             // Wave w looks after queries [QPW*w, QPW*(w+1)): re-select any whose buffer
             // could overflow on the next tile (a tile adds at most TM entries).
             if (tid < TN) shared_lds[tid] = unorder_f32(pending_floor | (pending_floor == 0 ? 0x007fffffu : 0u));
-            const int c = cnt_lds[wave * QPW + (lane % QPW)];
-            unsigned long long need = __ballot(lane < QPW && c + TM > CAP);  // k + slack + TM <= CAP by plan
-            if (a.debug_no_candidates & 2) need = 0;
-            if ((a.debug_no_candidates & 4) && lane == 0 && need) atomicAdd(a.debug_counters + 1, (unsigned long long)__popcll(need));
-            while (need) {
-                const int j = __ffsll((long long)need) - 1;
-                need &= need - 1;
-                const int q = wave * QPW + j;
-                const int cq = __builtin_amdgcn_readfirstlane(cnt_lds[q]);
-                compact_query<E>(my_buf + (size_t)q * CAP, cq, a.k, a.slack, floor_lds, cnt_lds, q, lane,
-                                 shared_floor + q, hist_lds);
-            }
+            reselect_where_full<CAP>(wave * QPW, QPW, TM, lane, a, floor_lds, cnt_lds, my_buf, shared_floor, hist_lds);
             ks = 0;
             ++tile;
             ptile = ptile_next;
@@ -439,32 +490,7 @@ __global__ __launch_bounds__(kThreads, 2) void score_topk_mfma_kernel(MfmaArgs a
     if constexpr (MAX_ONLY) return;
     // Final selection per query and one candidate list per (query, range).
     __syncthreads();
-    for (int j = 0; j < QPW; ++j) {
-        const int q = wave * QPW + j;
-        const int qg = qt * TN + q;
-        if (qg >= a.b) continue;  // wave-uniform
-        int cq = __builtin_amdgcn_readfirstlane(cnt_lds[q]);
-        unsigned long long* buf = my_buf + (size_t)q * CAP;
-        if (cq > a.k) {
-            compact_query<E>(buf, cq, a.k, 0, floor_lds, cnt_lds, q, lane, shared_floor + q, hist_lds);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            cq = __builtin_amdgcn_readfirstlane(cnt_lds[q]);
-        }
-        float* os = a.out_s + ((size_t)qg * a.n_ranges + range) * a.k;
-        int* oi = a.out_i + ((size_t)qg * a.n_ranges + range) * a.k;
-        for (int i = lane; i < a.k; i += 64) {
-            if (i < cq) {
-                const unsigned long long key = buf[i];
-                os[i] = key_score(key);
-                oi[i] = key_row(key);
-            } else {
-                os[i] = -__builtin_huge_valf();
-                oi[i] = -1;
-            }
-        }
-    }
+    write_range_lists<CAP>(wave * QPW, QPW, qt * TN, range, lane, a, floor_lds, cnt_lds, my_buf, shared_floor, hist_lds);
 }
 
 }  // namespace
