@@ -35,6 +35,15 @@ struct MergeArgs {
     long long* out_i;
     float* out_s;
     int heads_first;  // lists are sorted: use the list heads to bound the k-th best first
+    // Key-list form (merge_select_kernel only): list l of query q holds
+    // min(key_counts[...], k_in) entries  row | score bits << 32  instead of (score, id) pairs.
+    // Lists come in groups of key_subs (one group per producing workgroup).
+    const unsigned long long* keys;   // [query tile][n_lists / key_subs][256][key_subs][k_in]
+    const unsigned int* key_counts;   // [query tile][n_lists / key_subs][256][key_subs]
+    int key_subs;
+    int* overflow;                    // set to 1 when a count exceeds k_in
+    int key_rows;                     // keys of rows >= key_rows (tile padding) are dropped
+    const int* run_if;                // not NULL: the kernel does nothing while *run_if == 0
 };
 
 struct Cand {
@@ -73,6 +82,7 @@ __device__ __forceinline__ void fold_wave_lists(WaveTopK<long long>& tk, const f
 constexpr int kQueueCap = 512;  // survivors staged in LDS for wave 0
 
 __global__ void merge_topk_kernel(MergeArgs a) {
+    if (a.run_if && *a.run_if == 0) return;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nwaves = blockDim.x >> 6;
     long long* list_i = reinterpret_cast<long long*>(smem);
@@ -196,18 +206,21 @@ __device__ __forceinline__ int select_into(const unsigned long long (&key)[kSelE
 }
 
 __global__ void merge_select_kernel(MergeArgs a) {
+    if (a.run_if && *a.run_if == 0) return;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nwaves = blockDim.x >> 6;
     const int k = a.k_out;
-    unsigned long long* lists = reinterpret_cast<unsigned long long*>(smem);           // [nwaves][k]
-    unsigned int* hist_all = reinterpret_cast<unsigned int*>(lists + (size_t)nwaves * k);  // [nwaves][256]
+    // [nwaves][k]; key-list form: [nwaves][kSelSlots], new keys staged behind the k survivors
+    const int lstride = a.keys ? kSelSlots : k;
+    unsigned long long* lists = reinterpret_cast<unsigned long long*>(smem);
+    unsigned int* hist_all = reinterpret_cast<unsigned int*>(lists + (size_t)nwaves * lstride);  // [nwaves][256]
     int* cnt_lds = reinterpret_cast<int*>(hist_all + nwaves * 256);
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int q = blockIdx.x;
     const long long qbase = (long long)q * a.query_stride;
-    unsigned long long* my_list = lists + (size_t)wave * k;
+    unsigned long long* my_list = lists + (size_t)wave * lstride;
     unsigned int* hist = hist_all + wave * 256;
 
     // Level 0: each wave streams a contiguous slice of the candidates through
@@ -218,6 +231,50 @@ __global__ void merge_select_kernel(MergeArgs a) {
     const long long hi = lo + per_wave < total ? lo + per_wave : total;
     const int chunk = kSelSlots - k;  // new candidates per round (k <= 256, so >= 256)
     int cnt = 0;
+    if (a.keys) {
+        // Key lists: wave w takes lists w, w + nwaves, ... and copies their keys
+        // behind its survivors in LDS; whenever `chunk` new keys are staged (and
+        // at the end) survivors + staged keys -> select k.
+        const int groups = a.n_lists / a.key_subs;
+        int staged = 0;
+        auto select_round = [&]() {
+            unsigned long long key[kSelE];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int e = 0; e < kSelE; ++e) {
+                const int slot = e * 64 + lane;
+                key[e] = (slot < k ? slot < cnt : slot - k < staged) ? my_list[slot] : 0ull;
+            }
+            __builtin_amdgcn_wave_barrier();
+            cnt = select_into(key, k, my_list, hist, lane);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            staged = 0;
+        };
+        for (int l = wave; l < a.n_lists; l += nwaves) {
+            const size_t slot0 = (((size_t)(q >> 8) * groups + l / a.key_subs) * 256 + (q & 255)) * a.key_subs + l % a.key_subs;
+            unsigned int have = a.key_counts[slot0];
+            if (have > (unsigned int)a.k_in) {
+                if (lane == 0) *a.overflow = 1;
+                have = (unsigned int)a.k_in;
+            }
+            const unsigned long long* src = a.keys + slot0 * a.k_in;
+            int done = 0;
+            while (done < (int)have) {
+                const int take = (int)have - done < chunk - staged ? (int)have - done : chunk - staged;
+                for (int j = lane; j < take; j += 64) {
+                    const unsigned long long raw = src[done + j];  // row | score bits << 32
+                    const int row = (int)(unsigned int)raw;
+                    my_list[k + staged + j] = row < a.key_rows ? pack_key(__uint_as_float((unsigned int)(raw >> 32)), row) : 0ull;
+                }
+                staged += take;
+                done += take;
+                if (staged == chunk) select_round();
+            }
+        }
+        if (staged > 0) select_round();
+    } else
     for (long long c0 = lo; c0 < hi; c0 += chunk) {
         unsigned long long key[kSelE];
 #pragma unroll
@@ -259,7 +316,7 @@ __global__ void merge_select_kernel(MergeArgs a) {
                 const int j = slot / k;          // which list of my group
                 const int i = slot - j * k;
                 const int src = wave * fan + j;
-                key[e] = (j < fan && src < n && i < cnt_lds[src]) ? lists[(size_t)src * k + i] : 0ull;
+                key[e] = (j < fan && src < n && i < cnt_lds[src]) ? lists[(size_t)src * lstride + i] : 0ull;
             }
         }
         __syncthreads();
@@ -297,10 +354,11 @@ __global__ void merge_select_kernel(MergeArgs a) {
 
 hipError_t launch_merge_topk(const float* cand_s, const int* idx32, const long long* idx64, int n_lists,
                              long long list_stride, long long list_stride_s, long long query_stride, int k_in, int b, int k_out,
-                             long long idx_offset, long long* out_idx, float* out_score, hipStream_t stream) {
+                             long long idx_offset, long long* out_idx, float* out_score, hipStream_t stream,
+                             const int* run_if) {
     if (b < 1 || k_out < 1 || k_in < 1 || n_lists < 1) return hipErrorInvalidValue;
     MergeArgs a{cand_s, idx32, idx64, n_lists, list_stride, list_stride_s, query_stride, k_in, k_out, idx_offset, out_idx, out_score,
-                (n_lists >= 4 * k_out && n_lists >= 128) ? 1 : 0};
+                (n_lists >= 4 * k_out && n_lists >= 128) ? 1 : 0, nullptr, nullptr, 1, nullptr, 0, run_if};
     const long long total = (long long)n_lists * k_in;
     if (idx32 && k_out <= 256 && total > 64) {
         // one wave per 512-slot chunk of candidates, at most 16
@@ -315,6 +373,18 @@ hipError_t launch_merge_topk(const float* cand_s, const int* idx32, const long l
     while (nwaves > 1 && (size_t)nwaves * k_out * 12 + kQueueCap * 12 + 128 > 60 * 1024) nwaves /= 2;  // LDS budget
     const size_t lds = (size_t)nwaves * k_out * 12 + (size_t)kQueueCap * 12 + (size_t)nwaves * 4 + 16;
     hipLaunchKernelGGL(merge_topk_kernel, dim3(b), dim3(nwaves * 64), lds, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_select_keys(const unsigned long long* keys, const unsigned int* counts, int n_lists, int subs, int cap,
+                              int n_rows, int b, int k_out, long long idx_offset, long long* out_idx, float* out_score,
+                              int* overflow, hipStream_t stream) {
+    if (b < 1 || k_out < 1 || k_out > 256 || cap < 1 || n_lists < 1 || subs < 1 || n_lists % subs != 0) return hipErrorInvalidValue;
+    MergeArgs a{nullptr, nullptr, nullptr, n_lists, 0, 0, 0, cap, k_out, idx_offset, out_idx, out_score, 0,
+                keys, counts, subs, overflow, n_rows, nullptr};
+    const int nw = n_lists < 8 ? n_lists : 8;
+    const size_t lds_sel = (size_t)nw * kSelSlots * 8 + (size_t)nw * 1024 + (size_t)nw * 4 + 16;
+    hipLaunchKernelGGL(merge_select_kernel, dim3(b), dim3(nw * 64), lds_sel, stream, a);
     return hipGetLastError();
 }
 

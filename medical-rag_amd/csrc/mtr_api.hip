@@ -103,6 +103,8 @@ struct mtr_index {
     DevBuf mfma_cand;  // its workgroups' candidate buffers
     DevBuf mfma_floor; // per-query floor shared by the row ranges
     DevBuf tile_max;   // the sampling launch's best score per (query, sampled tile)
+    DevBuf wide_keys;  // the 256 x 256-tile kernel's key lists ...
+    DevBuf wide_counts; // ... their counts, and one more word: the overflow flag
     DevBuf out_i, out_s;
     DevBuf stage;      // staging for host rows
     void* pinned = nullptr;
@@ -160,6 +162,13 @@ int sample_stride(long long n, long long n_tiles, int k) {
     return s >= 2 ? (int)s : 0;
 }
 
+// Smallest batch that goes to the 256 x 256-tile kernel (bf16 shards large
+// enough for a sampling launch); read on every search, so that tests can switch it.
+int wide_min_batch() {
+    const char* e = getenv("MTR_WIDE_MIN_BATCH");
+    return e ? atoi(e) : 512;
+}
+
 // Matrix-core path: queries converted to the shard's type, fused score + top-k
 // launch, then the merge of the per-range lists.
 int enqueue_mfma(mtr_index* ix, const mtr::MfmaPlan& plan, const void* dev_queries, int q_dtype, int b, int k,
@@ -181,8 +190,18 @@ int enqueue_mfma(mtr_index* ix, const mtr::MfmaPlan& plan, const void* dev_queri
         if (mtr::plan_mfma(ix->dtype, n_samp * plan.tm, ix->ld, b, k, ix->num_cus, &samp) != 0)
             return fail(MTR_ERR_INVALID, "internal: no launch shape for the sampling launch");
     }
+    // Large batches on bf16 shards: the sampling launch's floors feed the
+    // 256 x 256-tile filter kernel, which appends every score that reaches its
+    // query's floor (about k * stride per query: the floor is the k-th largest of
+    // n_tiles / stride tile maxima); the general kernel is enqueued behind it and
+    // runs only if a key list overflowed.
+    mtr::WidePlan wide;
+    const bool use_wide =
+        stride >= 2 && ix->dtype == MTR_BF16 && b >= wide_min_batch() &&
+        mtr::plan_wide(ix->dtype, ix->n, ix->ld, b, k, (int)std::min<long long>(1 << 24, (long long)std::max(4 * k, 20) * stride),
+                       ix->num_cus, &wide) == 0;
     const size_t q_row_bytes = (size_t)ix->ld * dtype_size(ix->dtype);
-    const int64_t q_rows = (int64_t)plan.n_qtiles * plan.tnq;
+    const int64_t q_rows = std::max<int64_t>((int64_t)plan.n_qtiles * plan.tnq, use_wide ? (int64_t)wide.n_qtiles * 256 : 0);
     const size_t qbytes = (size_t)q_rows * q_row_bytes;
     const void* q_before = ix->q_bf16.p;
     if ((rc = ix->q_bf16.reserve(qbytes)) != MTR_OK) return rc;
@@ -192,6 +211,10 @@ int enqueue_mfma(mtr_index* ix, const mtr::MfmaPlan& plan, const void* dev_queri
     if ((rc = ix->cand_i.reserve((size_t)b * plan.n_ranges * k * 4)) != MTR_OK) return rc;
     const int floor_words = plan.n_qtiles * plan.tnq;
     if ((rc = ix->mfma_floor.reserve((size_t)floor_words * 4)) != MTR_OK) return rc;
+    if (use_wide) {
+        if ((rc = ix->wide_keys.reserve(wide.key_bytes)) != MTR_OK) return rc;
+        if ((rc = ix->wide_counts.reserve((wide.count_words + 1) * 4)) != MTR_OK) return rc;
+    }
     if (stride >= 2 && (rc = ix->tile_max.reserve((size_t)floor_words * samp.n_tiles * 4)) != MTR_OK) return rc;
     // The sampling launch's floor kernel sets every real query's floor; otherwise they start from zero.
     if (stride < 2) HIP_TRY(hipMemsetAsync(ix->mfma_floor.p, 0, (size_t)floor_words * 4, stream));
@@ -227,18 +250,29 @@ int enqueue_mfma(mtr_index* ix, const mtr::MfmaPlan& plan, const void* dev_queri
     int* lists_i = static_cast<int*>(ix->cand_i.p);
     if (stride >= 2) {
         unsigned int* tile_max = static_cast<unsigned int*>(ix->tile_max.p);
-        const mtr::MfmaPass sampling{stride, tile_max};
+        const mtr::MfmaPass sampling{stride, tile_max, nullptr};
         HIP_TRY(mtr::launch_score_mfma(ix->rows, ix->dtype, ix->n, ix->ld, ix->q_bf16.p, b, k, samp, sampling,
                                        ix->mfma_cand.p, floors, lists_s, lists_i, stream));
         HIP_TRY(mtr::launch_floor_from_tile_max(tile_max, (int)samp.n_tiles, b, k, floors, stream));
     }
-    const mtr::MfmaPass all{1, nullptr};
+    int* overflow = nullptr;
+    if (use_wide) {
+        unsigned int* counts = static_cast<unsigned int*>(ix->wide_counts.p);
+        unsigned long long* keys = static_cast<unsigned long long*>(ix->wide_keys.p);
+        overflow = reinterpret_cast<int*>(counts + wide.count_words);
+        HIP_TRY(hipMemsetAsync(overflow, 0, 4, stream));
+        HIP_TRY(mtr::launch_score_wide(ix->rows, ix->n, ix->ld, ix->q_bf16.p, b, wide, floors, keys, counts, stream));
+        if (ix->profiling) HIP_TRY(hipEventRecord(e1, stream));
+        HIP_TRY(mtr::launch_select_keys(keys, counts, wide.n_lists * mtr::kWideSubs, mtr::kWideSubs, wide.cap, (int)ix->n, b, k, ix->row_offset, dev_out_idx,
+                                        dev_out_score, overflow, stream));
+    }
+    const mtr::MfmaPass all{1, nullptr, overflow};
     HIP_TRY(mtr::launch_score_mfma(ix->rows, ix->dtype, ix->n, ix->ld, ix->q_bf16.p, b, k, plan, all, ix->mfma_cand.p,
                                    floors, lists_s, lists_i, stream));
-    if (ix->profiling) HIP_TRY(hipEventRecord(e1, stream));
+    if (ix->profiling && !use_wide) HIP_TRY(hipEventRecord(e1, stream));
     HIP_TRY(mtr::launch_merge_topk(lists_s, lists_i, nullptr, plan.n_ranges, (long long)k, (long long)k,
                                    (long long)plan.n_ranges * k, k, b, k, ix->row_offset, dev_out_idx, dev_out_score,
-                                   stream));
+                                   stream, overflow));
     return MTR_OK;
 }
 
@@ -572,6 +606,8 @@ void mtr_index_destroy(mtr_index_t* ix) {
         ix->mfma_cand.release();
         ix->mfma_floor.release();
         ix->tile_max.release();
+        ix->wide_keys.release();
+        ix->wide_counts.release();
         ix->out_i.release();
         ix->out_s.release();
         ix->stage.release();

@@ -78,11 +78,12 @@ hipError_t launch_scan_topk(const void* rows, int dtype, int64_t n, int ld, int 
 // candidates.  Candidate (list l, query q, slot j) sits at
 // l*list_stride + q*query_stride + j (list_stride_s for the scores).  idx32 != NULL: 32-bit local rows, to
 // which idx_offset is added; else idx64.  Entries with id < 0 are padding.
+// run_if != NULL: the kernel does nothing while that device word is 0.
 hipError_t launch_merge_topk(const float* cand_s, const int* idx32, const long long* idx64,
                              int n_lists, long long list_stride, long long list_stride_s,
                              long long query_stride, int k_in,
                              int b, int k_out, long long idx_offset, long long* out_idx,
-                             float* out_score, hipStream_t stream);
+                             float* out_score, hipStream_t stream, const int* run_if = nullptr);
 
 // Masked mean pooling over tokens + L2 normalisation of encoder outputs:
 // hidden [b][t][d] (dtype 0 fp32, 2 bf16, 3 fp16), mask [b][t] int64 -> out [b][d] fp32.
@@ -116,6 +117,7 @@ constexpr int kMaxSampleTiles = 1024;
 struct MfmaPass {
     int tile_stride;
     unsigned int* tile_max;   // [n_qtiles*tnq][plan.n_tiles] order-preserving score bits, or NULL
+    const int* run_if;        // not NULL: the launch does nothing while this device word is 0
 };
 
 // rows x queries on the matrix cores with fused top-k, both in the shard's storage type
@@ -132,5 +134,41 @@ hipError_t launch_score_mfma(const void* rows, int dtype, int64_t n, int ld, con
 // more than k tiles); n_tiles <= kMaxSampleTiles.
 hipError_t launch_floor_from_tile_max(const unsigned int* tile_max, int n_tiles, int b, int k,
                                       unsigned int* shared_floor, hipStream_t stream);
+
+constexpr int kWideSubs = 4;  // key lists per (workgroup, query): one per lane that holds the query's scores
+struct WidePlan {
+    int n_qtiles;             // query tiles of 256
+    int n_lists;              // interleaved row lists (workgroups per query tile)
+    long long n_tiles;        // row tiles of 256
+    int grid;
+    size_t lds;
+    int cap;                  // key slots per list; every (workgroup, query) pair has kWideSubs lists
+    size_t key_bytes;         // [n_qtiles][n_lists][256][kWideSubs][cap] packed keys
+    size_t count_words;       // [n_qtiles][n_lists][256][kWideSubs]
+};
+
+// Launch shape of the 256 x 256-tile filter kernel (bf16 shards, large
+// batches); -1 when the shape is not covered.  expected_hits: how many scores
+// per query the given floors are expected to let through.
+int plan_wide(int dtype, int64_t n, int ld, int b, int k, int expected_hits, int num_cus, WidePlan* plan);
+
+// rows x queries on the matrix cores; every score >= its query's floor
+// (floors[q], order-preserving bits as written by launch_floor_from_tile_max)
+// is appended as  row | score bits << 32  to keys[query tile][list][query][sub][0..cap)
+// (rows past n in the last tile included, as copies of the last row), and
+// counts[...][sub] receives how many reached the floor (more than cap: the list
+// is incomplete).  queries: [n_qtiles*256][ld] bf16, rows past b zero.
+hipError_t launch_score_wide(const void* rows, int64_t n, int ld, const void* queries, int b, const WidePlan& plan,
+                             const unsigned int* floors, unsigned long long* keys, unsigned int* counts,
+                             hipStream_t stream);
+
+// The best k_out of each query's key lists written by launch_score_wide, in
+// (score descending, row ascending) order, ignoring keys of rows >= n_rows (the
+// last tile's padding); *overflow is set to 1 when a list of any query was
+// incomplete (the outputs of that query are then not valid).
+// n_lists lists per query in groups of subs ([query tile][n_lists / subs][256][subs][cap]).
+hipError_t launch_select_keys(const unsigned long long* keys, const unsigned int* counts, int n_lists, int subs, int cap,
+                              int n_rows, int b, int k_out, long long idx_offset, long long* out_idx, float* out_score, int* overflow,
+                              hipStream_t stream);
 
 }  // namespace mtr

@@ -86,6 +86,7 @@ struct MfmaArgs {
     unsigned int* shared_floor;    // [n_qtiles*TN] order-preserving score bits, zeroed before the launch
     float* out_s;            // [b][n_ranges][k]
     int* out_i;
+    const int* run_if;       // not NULL: do nothing while *run_if == 0
 };
 
 template <int AUX, int ROWS, int WAVES>
@@ -337,6 +338,7 @@ __device__ __forceinline__ void write_range_lists(int q0, int nq, int qt_base, i
 // the compiler copy all accumulators after every K step.
 template <typename T, int CAP, int TNQ, bool MAX_ONLY>
 __global__ __launch_bounds__(kThreads, 2) void score_topk_mfma_kernel(MfmaArgs a) {
+    if (a.run_if && *a.run_if == 0) return;
     constexpr int TN = TNQ;
     constexpr int WAVES = kThreads / 64;
     constexpr int WN = TNQ == 32 ? 1 : 2;                   // waves along the queries
@@ -566,6 +568,7 @@ hipError_t launch_score_mfma(const void* rows, int dtype, int64_t n, int ld, con
     a.shared_floor = shared_floor;
     a.out_s = out_s;
     a.out_i = out_i;
+    a.run_if = pass.run_if;
     auto launch = [&](auto kernel) -> hipError_t {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds);

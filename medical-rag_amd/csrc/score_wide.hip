@@ -1,0 +1,368 @@
+// Large-batch scoring of a bf16 shard on the matrix cores: 256 rows x 256
+// queries per tile, eight waves, and nothing in the loop but a threshold test.
+//
+// Same job as score_mfma.hip (the many-queries form of retrieve_top_index,
+// pipeline/utils/local_rag.py:76-78, for the batch built at
+// pipeline/async_main.py:193-195), for batches of hundreds of queries and more,
+// where the 128 x 128 tile of that kernel is bound by what one CU can move from
+// L2 into LDS: a 256 x 256 tile needs half the bytes per flop.
+//
+// The price of the larger tile is registers: 128 accumulators per lane plus
+// the operand fragments leave no room for the in-loop re-selection that
+// score_mfma.hip uses to keep its candidate buffers short (the compiler spills,
+// and a reload stalls the direct-to-LDS loads behind it).  So this kernel
+// keeps no floor of its own.  It takes each query's floor as an input -- the
+// k-th largest of the per-tile best scores of a sampling launch, which k
+// different rows reach, so no row below it can be among the k best -- and
+// appends every score that reaches the floor, as (row, score bits),
+// to a list private to the lane (four lanes of a workgroup hold a query's
+// scores: four lists per workgroup and query), counting in a register.  A
+// list that overflows keeps counting; the selection kernel that follows
+// (merge_topk.hip, launch_select_keys) sees the count, raises a flag, and the
+// caller's already enqueued launch of the general kernel, which does nothing
+// unless the flag is set, recomputes the batch.  Results are exact either way.
+//
+// Work split.  One workgroup per (query tile, row list); row list r of R holds
+// tiles r, r + R, r + 2R, ...: neighbouring rows are often about the same
+// subject (pages of one book), and interleaving spreads a query's hits evenly
+// over the lists, which is what sizes the buffers.
+//
+// Tile.  Waves 2 x 4: wave (wm, wn) owns rows [128 wm, +128) x queries
+// [64 wn, +64) as 4 x 2 MFMA tiles of 32 x 32 (v_mfma_f32_32x32x16_bf16), K
+// steps of 64 elements.  LDS holds two K steps, each as four half tiles of 128
+// rows x 128 bytes (rows 0-127, rows 128-255, queries 0-127, queries 128-255),
+// filled by 16-byte direct-to-LDS loads whose 16-byte chunks are XOR-swizzled
+// with the row number on the source address.  The two wave groups (wm = 0, 1)
+// run one barrier apart, so that one is on the matrix cores while the other
+// reads LDS.  Every wave executes the same barrier sequence, three per K step;
+// group 1 executes one extra barrier first and group 0 one extra at the end.
+// In group-0 barrier slots, step s: slot 3s (then it reads its query and low
+// row fragments), 3s+1 (MFMA low, reads high rows), 3s+2 (MFMA high); group 1
+// does the same at 3s+1, 3s+2, 3s+3.
+//   landed:  the query halves of step s+1 are loaded by all eight waves; each
+//            waits for its part before its LAST barrier of step s, i.e. before
+//            slot 3s+3 at the latest, and the first reader starts after 3s+3.
+//            A row half is loaded and read by ONE group: its waves wait before
+//            their first barrier of step s+1.
+//   refill:  after its last barrier of step s a wave requests the queries and
+//            its group's rows of step s+2 into the buffers step s used: group 0
+//            after slot 3s+2, when group 1 finished its query reads (before its
+//            second barrier = 3s+2); a group's row reads end before its own
+//            last barrier.
+// Waits on the loads are counted (s_waitcnt vmcnt(N)).  Loads return in order,
+// so "at most N operations outstanding" implies that all but the newest N loads
+// have landed, whatever the appends' stores (which may complete in any order
+// relative to loads) contribute to the count: they only make a wait longer.
+//
+// Algorithmic work per launch: 2 * B * n * d flops (fp32 accumulate).
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "mtr_device.h"
+#include "wave_select.h"
+
+namespace mtr {
+
+namespace {
+
+constexpr int kWideThreads = 512;
+constexpr int kWideTile = 256;                  // rows per tile = queries per tile
+constexpr int kHalfBytes = 128 * 128;           // 128 rows x 128 bytes
+constexpr int kWideStepBytes = 4 * kHalfBytes;  // rows lo, rows hi, queries lo, queries hi
+constexpr size_t kWideLds = 2 * kWideStepBytes;
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+struct WideArgs {
+    const char* rows;         // [n][ld] bf16
+    long long n;
+    int ld;                   // elements, a multiple of 64
+    const char* queries;      // [n_qtiles*256][ld] bf16, zero rows past b
+    int b;
+    int n_lists;              // row lists (workgroups per query tile)
+    long long n_tiles;
+    const unsigned int* floor;    // [b] order-preserving score bits (0: no floor)
+    unsigned long long* keys;     // [n_qtiles][n_lists][256][kWideSubs][cap]: row | (unsigned long long)score bits << 32
+    unsigned int* counts;         // [n_qtiles][n_lists][256][kWideSubs] scores that reached the floor (may exceed cap)
+    int cap;
+    int debug;                // timing experiments only: bit 0 nothing reaches the floor
+};
+
+// This wave's share (4 of 32 instructions) of the two query halves of a K step.
+__device__ __forceinline__ void request_queries(const char* qbase, long long row_bytes, int k0_bytes, char* dst, int wave,
+                                                int lane) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int t = wave * 2 + i;
+            const int r = h * 128 + t * 8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ (lane >> 3);
+            const char* src = qbase + r * row_bytes + k0_bytes + chunk * 16;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(dst + (2 + h) * kHalfBytes + t * 1024), 16, 0, 0);
+        }
+}
+
+// ... and of ITS GROUP's row half (16 instructions over the group's 4 waves).
+// Rows past the end of the matrix are fetched as copies of the last row.
+__device__ __forceinline__ void request_rows(const char* rows, long long row0, long long row_max, long long row_bytes,
+                                             int k0_bytes, char* dst, int wave_in_group, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int t = wave_in_group * 4 + i;
+        long long row = row0 + t * 8 + (lane >> 3);
+        row = row < row_max ? row : row_max;
+        const int chunk = (lane & 7) ^ (lane >> 3);
+        const char* src = rows + row * row_bytes + k0_bytes + chunk * 16;
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(dst + t * 1024), 16, 0, 0);
+    }
+}
+
+__device__ __forceinline__ bf16x8 read_frag(const char* lds, int row, int chunk) {
+    return *reinterpret_cast<const bf16x8*>(lds + row * 128 + ((chunk ^ (row & 7)) << 4));
+}
+
+// s_barrier without the drain of outstanding loads that __syncthreads() adds.
+__device__ __forceinline__ void barrier_keeping_loads() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+__global__ __launch_bounds__(kWideThreads, 2) void score_filter_wide_kernel(WideArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    // XCD-aware, bijective workgroup remap: ids that land on one XCD become consecutive.
+    const int nwg = gridDim.x, xcd = blockIdx.x % 8, per = nwg / 8, rem = nwg % 8;
+    const int wgid = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + blockIdx.x / 8;
+    const int qt = wgid / a.n_lists, list = wgid % a.n_lists;
+    long long my_tiles = a.n_tiles > list ? (a.n_tiles - list + a.n_lists - 1) / a.n_lists : 0;
+    long long tile_step = a.n_lists, tile_first = list;
+    if (a.debug & 2) {  // contiguous ranges
+        const long long tpr = (a.n_tiles + a.n_lists - 1) / a.n_lists;
+        tile_first = list * tpr;
+        tile_step = 1;
+        my_tiles = a.n_tiles - tile_first < tpr ? a.n_tiles - tile_first : tpr;
+        if (my_tiles < 0) my_tiles = 0;
+    }
+    const int ksteps = a.ld / 64;
+    const long long row_bytes = (long long)a.ld * 2;
+    const char* qbase = a.queries + (size_t)qt * kWideTile * row_bytes;
+    const long long total = my_tiles * ksteps;
+
+    // This lane's two queries (accumulator column = lane & 31) and their floors.
+    float thr[2];
+#pragma unroll
+    for (int nn = 0; nn < 2; ++nn) {
+        const int q = qt * kWideTile + wn * 64 + nn * 32 + (lane & 31);
+        thr[nn] = __builtin_huge_valf();  // padding queries collect nothing
+        if (q < a.b && !(a.debug & 1)) {
+            const unsigned int f = a.floor[q];
+            thr[nn] = unorder_f32(f | (f == 0 ? 0x007fffffu : 0u));  // no floor: -inf
+        }
+    }
+    // The floors must have arrived before the first tile load is requested: the
+    // loop's counted waits assume that nothing else is in flight.
+    asm volatile("" ::"v"(thr[0]), "v"(thr[1]) : "memory");
+
+    // load cursor: the next K step to request
+    long long ld_tile = tile_first;
+    int ld_ks = 0, ld_buf = 0;
+    auto request_step = [&]() {
+        char* dst = smem + ld_buf * kWideStepBytes;
+        request_queries(qbase, row_bytes, ld_ks * 128, dst, wave, lane);
+        request_rows(a.rows, ld_tile * kWideTile + wm * 128, a.n - 1, row_bytes, ld_ks * 128, dst + wm * kHalfBytes, wn, lane);
+        ld_buf ^= 1;
+        if (++ld_ks == ksteps) { ld_ks = 0; ld_tile += tile_step; }
+    };
+    if (total > 0) request_step();
+    if (total > 1) request_step();
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][nn][r] = 0.f;
+
+    // step 0 has landed for everybody; then group 1 falls one barrier behind
+    if (total > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    barrier_keeping_loads();
+    if (wm == 1) barrier_keeping_loads();
+
+    // Each query's scores of a tile sit in four lanes of the workgroup (wm = 0, 1 x
+    // lane / 32 = 0, 1); each of them appends to a list of its own and counts in a
+    // register.
+    const int sub = wm * 2 + (lane >> 5);
+    unsigned long long* my_keys = a.keys + ((size_t)wgid * kWideTile * kWideSubs + sub) * a.cap;
+    int cnt[2] = {0, 0};
+    const int cap_mask = a.cap - 1;  // cap is a power of two
+    long long tile = tile_first;
+    int ks = 0;
+    for (long long s = 0; s < total; ++s) {
+        const char* buf = smem + (int)(s & 1) * kWideStepBytes;
+        const char* sa = buf + wm * kHalfBytes;
+        const char* sb = buf + (2 + (wn >> 1)) * kHalfBytes;
+        const int qrow = (wn & 1) * 64;
+        // this group's rows of step s (its queries were waited for before the previous barrier)
+        if (s > 0) {
+            if (s + 1 < total) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        barrier_keeping_loads();                                   // first barrier of the step
+        bf16x8 fb[2][4], fa[2][4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int nn = 0; nn < 2; ++nn) fb[nn][kk] = read_frag(sb, qrow + nn * 32 + (lane & 31), 2 * kk + (lane >> 5));
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) fa[m][kk] = read_frag(sa, m * 32 + (lane & 31), 2 * kk + (lane >> 5));
+        barrier_keeping_loads();                                   // second barrier
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int nn = 0; nn < 2; ++nn)
+                    acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m][kk], fb[nn][kk], acc[m][nn], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) fa[m][kk] = read_frag(sa, 64 + m * 32 + (lane & 31), 2 * kk + (lane >> 5));
+        // the queries of step s + 1: the older four of the eight loads in flight
+        if (s + 1 < total) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        barrier_keeping_loads();                                   // third barrier
+        // On a tile's last K step the request waits until the tile's appends are
+        // issued: a store behind eight 1 KiB loads stalls the wave until the
+        // memory pipeline has taken them.
+        const bool tile_done = ks + 1 == ksteps;
+        if (!tile_done && s + 2 < total) request_step();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int nn = 0; nn < 2; ++nn)
+                    acc[2 + m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m][kk], fb[nn][kk], acc[2 + m][nn], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+
+        if (ks + 1 == ksteps) {
+            // The tile's scores are complete.  Accumulator register r of MFMA tile m
+            // holds row 32 m + 8 (r / 4) + 4 (lane / 32) + r % 4 of the wave's 128.
+            // Rows past the end of the matrix (copies of the last row, in the last tile
+            // only) are appended like any other; the selection kernel drops them.
+            const int row_base = (int)(tile * kWideTile) + wm * 128 + 4 * (lane >> 5);
+            if (a.debug & 4) {
+#pragma unroll
+                for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[m][nn][r] = 0.f;
+            } else
+#pragma unroll
+            for (int nn = 0; nn < 2; ++nn) {
+                const int ql = wn * 64 + nn * 32 + (lane & 31);
+                unsigned long long* qkeys = my_keys + (size_t)ql * kWideSubs * a.cap;
+                // Three scores per test (v_max3): a branch costs more than the compare,
+                // and with some thousand scores per query reaching the floor, about one
+                // group in three holds one in some lane.
+#pragma unroll
+                for (int g = 0; g < 64; g += 3) {
+                    float mx = acc[g >> 4][nn][g & 15];
+#pragma unroll
+                    for (int j = g + 1; j < g + 3 && j < 64; ++j) mx = fmaxf(mx, acc[j >> 4][nn][j & 15]);
+                    if (__builtin_expect(mx >= thr[nn], 0)) {
+#pragma unroll
+                        for (int j = g; j < g + 3 && j < 64; ++j) {
+                            const float v = acc[j >> 4][nn][j & 15];
+                            if (v >= thr[nn]) {
+                                // (raw score bits, row), wrapping around in a full list: the count
+                                // tells the selection kernel that the list is incomplete.
+                                using u32x2 = __attribute__((ext_vector_type(2))) unsigned int;
+                                *reinterpret_cast<u32x2*>(qkeys + (cnt[nn] & cap_mask)) =
+                                    u32x2{(unsigned int)(row_base + (j >> 4) * 32 + ((j & 15) >> 2) * 8 + (j & 3)), __float_as_uint(v)};
+                                ++cnt[nn];
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[m][nn][r] = 0.f;
+            }
+            if (s + 2 < total) request_step();
+            ks = 0;
+            tile += tile_step;
+        } else {
+            ++ks;
+        }
+    }
+    if (wm == 0) barrier_keeping_loads();   // group 0 catches up with group 1's last barrier
+#pragma unroll
+    for (int nn = 0; nn < 2; ++nn) {
+        const int ql = wn * 64 + nn * 32 + (lane & 31);
+        a.counts[((size_t)wgid * kWideTile + ql) * kWideSubs + sub] = (unsigned int)cnt[nn];
+    }
+}
+
+}  // namespace
+
+int plan_wide(int dtype, int64_t n, int ld, int b, int k, int expected_hits, int num_cus, WidePlan* plan) {
+    if (dtype != 2 || ld % 64 != 0 || ld < 128 || b < 1 || k < 1 || k > 256 || n < 1 || n > 0x7fffffffLL) return -1;
+    plan->n_qtiles = (b + kWideTile - 1) / kWideTile;
+    plan->n_tiles = (n + kWideTile - 1) / kWideTile;
+    long long lists = num_cus / plan->n_qtiles;  // one workgroup per CU
+    if (lists > plan->n_tiles) lists = plan->n_tiles;
+    if (lists < 1) lists = 1;
+    plan->n_lists = (int)lists;
+    plan->grid = plan->n_qtiles * plan->n_lists;
+    plan->lds = kWideLds;
+    // Slots per list: twice its even share of the hits the floor is expected to
+    // let through, a power of two between 128 and 8192.
+    long long want = 2LL * expected_hits / ((long long)plan->n_lists * kWideSubs);
+    int cap = 128;
+    while (cap < want && cap < 8192) cap *= 2;
+    plan->cap = cap;
+    plan->key_bytes = (size_t)plan->grid * kWideTile * kWideSubs * cap * 8;
+    plan->count_words = (size_t)plan->grid * kWideTile * kWideSubs;
+    return 0;
+}
+
+hipError_t launch_score_wide(const void* rows, int64_t n, int ld, const void* queries, int b, const WidePlan& plan,
+                             const unsigned int* floors, unsigned long long* keys, unsigned int* counts,
+                             hipStream_t stream) {
+    WideArgs a;
+    a.rows = static_cast<const char*>(rows);
+    a.n = n;
+    a.ld = ld;
+    a.queries = static_cast<const char*>(queries);
+    a.b = b;
+    a.n_lists = plan.n_lists;
+    a.n_tiles = plan.n_tiles;
+    a.floor = floors;
+    a.keys = keys;
+    a.counts = counts;
+    a.cap = plan.cap;
+    a.debug = getenv("MTR_WIDE_DEBUG") ? atoi(getenv("MTR_WIDE_DEBUG")) : 0;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter_wide_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(score_filter_wide_kernel, dim3(plan.grid), dim3(kWideThreads), plan.lds, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace mtr

@@ -458,6 +458,69 @@ def test_sampled_two_launch_search_equals_single_launch(native, store, stride):
     shard.close()
 
 
+def _search_with_env(shard, queries, k, **env):
+    """One search with the given environment switches set (the library reads them on every search)."""
+    import os
+    old = {name: os.environ.get(name) for name in env}
+    try:
+        for name, value in env.items():
+            os.environ[name] = str(value)
+        return shard.search(queries, k=k)
+    finally:
+        for name, value in old.items():
+            if value is None:
+                os.environ.pop(name, None)
+            else:
+                os.environ[name] = value
+
+
+@pytest.mark.parametrize("b", [3, 37, 256, 300])
+@pytest.mark.parametrize("stride", [2, 5])
+def test_wide_tile_kernel_equals_general_kernel(native, b, stride):
+    """Large batches on large bf16 shards go through the 256 x 256-tile filter
+    kernel (floors from the sampling launch, every score that reaches its floor
+    appended, selection afterwards).  Forced here on a small shard and small
+    batches: identical to the general kernel's single launch, ties, a ragged
+    last tile and padding queries included."""
+    rng = np.random.default_rng(900 + b + stride)
+    n, d, k = 256 * 150 + 77, 256, 24
+    corpus = rng.standard_normal((n, d)).astype(np.float32)
+    queries = rng.standard_normal((b, d)).astype(np.float32)
+    for row in (256 * stride + 3, 256 * (stride + 1) + 9, n - 2):
+        corpus[row] = corpus[5]
+    queries[0] = corpus[5]
+    shard = native.DeviceShard.from_host(corpus, store_dtype="bf16")
+    one_i, one_s = _search_with_env(shard, queries, k, MTR_MFMA_SAMPLE_STRIDE=0)
+    wide_i, wide_s = _search_with_env(shard, queries, k, MTR_MFMA_SAMPLE_STRIDE=stride, MTR_WIDE_MIN_BATCH=1)
+    assert (one_i == wide_i).all() and (one_s == wide_s).all()
+    assert one_i[0, :4].tolist() == [5, 256 * stride + 3, 256 * (stride + 1) + 9, n - 2]
+    check_topk(wide_i, wide_s, orc.scores(queries, corpus), k, 2.0 ** -8)
+    shard.close()
+
+
+def test_wide_tile_kernel_overflow_falls_back(native):
+    """When more scores reach a floor than a key list holds (here: thousands of
+    bit-equal rows, which all tie with the floor), the general kernel recomputes
+    the batch: same result as without the wide kernel, lowest rows first."""
+    rng = np.random.default_rng(77)
+    n, d, b, k = 256 * 120, 128, 40, 10
+    corpus = rng.standard_normal((n, d)).astype(np.float32)
+    corpus[1000:9000] = corpus[7]          # 8000 copies: every one of them reaches query 0's floor
+    queries = rng.standard_normal((b, d)).astype(np.float32)
+    queries[0] = corpus[7]
+    shard = native.DeviceShard.from_host(corpus, store_dtype="bf16")
+    one_i, one_s = _search_with_env(shard, queries, k, MTR_MFMA_SAMPLE_STRIDE=0)
+    wide_i, wide_s = _search_with_env(shard, queries, k, MTR_MFMA_SAMPLE_STRIDE=4, MTR_WIDE_MIN_BATCH=1)
+    assert (one_i == wide_i).all() and (one_s == wide_s).all()
+    assert one_i[0].tolist() == [7] + list(range(1000, 1009))
+    # and a batch without such ties afterwards, on the same handle, takes the wide kernel alone again
+    queries2 = rng.standard_normal((b, d)).astype(np.float32)
+    a_i, a_s = _search_with_env(shard, queries2, k, MTR_MFMA_SAMPLE_STRIDE=0)
+    b_i, b_s = _search_with_env(shard, queries2, k, MTR_MFMA_SAMPLE_STRIDE=4, MTR_WIDE_MIN_BATCH=1)
+    assert (a_i == b_i).all() and (a_s == b_s).all()
+    shard.close()
+
+
 @pytest.mark.parametrize("store", ["bf16", "fp32"])
 def test_batches_of_changing_size_on_one_shard(native, store):
     """The shard keeps its query staging buffer between searches and clears
