@@ -277,6 +277,10 @@ def main():
         min_b = int(os.environ.get("MTR_MFMA_MIN_BATCH", "0") or 0) or (2 if store == "bf16" else 3)
         on_mfma = batch >= min_b and k <= 256 and (dim * esize) % 128 == 0 and dim * esize >= 256
         kernel = "score_topk_mfma_kernel" if on_mfma else "scan_topk_kernel"
+        # bf16 shards of >= 1 GB: batches above 128 take the 256 x 256-tile kernel behind the sampling launch
+        wide_min = int(os.environ.get("MTR_WIDE_MIN_BATCH", "129"))
+        if on_mfma and store == "bf16" and batch >= wide_min and local_bytes >= 1.0e9:
+            kernel = "score_filter_wide_kernel"
         flops = 2.0 * batch * (hi - lo) * dim
         peak_tf = MFMA_PEAK_TFLOPS[store]
         # the roofline that binds is the one whose minimum time is longer

@@ -524,7 +524,8 @@ int plan_mfma(int dtype, int64_t n, int ld, int b, int k, int num_cus, MfmaPlan*
     // 128-query tiles.
     long long per_cu = plan->tnq == 32 ? 3 : 2;
     if (const char* e = getenv("MTR_MFMA_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
-    long long ranges = (per_cu * num_cus + plan->n_qtiles - 1) / plan->n_qtiles;
+    // rounded down: a grid a few workgroups above per_cu * CUs runs those in a second round
+    long long ranges = per_cu * num_cus / plan->n_qtiles;
     if (ranges > n_tiles) ranges = n_tiles;
     if (ranges < 1) ranges = 1;
     plan->tiles_per_range = (n_tiles + ranges - 1) / ranges;

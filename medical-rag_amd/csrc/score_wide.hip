@@ -336,6 +336,9 @@ int plan_wide(int dtype, int64_t n, int ld, int b, int k, int expected_hits, int
     long long want = 2LL * expected_hits / ((long long)plan->n_lists * kWideSubs);
     int cap = 128;
     while (cap < want && cap < 8192) cap *= 2;
+    // ... and at most 4 GiB of lists in all (large shards have long sample strides;
+    // their lists are long enough for a smaller margin to do)
+    while (cap > 128 && (size_t)plan->grid * kWideTile * kWideSubs * cap * 8 > ((size_t)4 << 30)) cap /= 2;
     plan->cap = cap;
     plan->key_bytes = (size_t)plan->grid * kWideTile * kWideSubs * cap * 8;
     plan->count_words = (size_t)plan->grid * kWideTile * kWideSubs;

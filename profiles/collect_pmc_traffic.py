@@ -10,7 +10,7 @@ import subprocess
 import sys
 
 STEPS, WARMUP = 3, 1
-KERNEL = {"c4": "scan_topk_kernel", "c2": "scan_topk_kernel", "c3": "score_topk_mfma_kernel"}
+KERNEL = {"c4": "scan_topk_kernel", "c2": "scan_topk_kernel", "c3": "score_"}  # c3: sampling launch (score_topk_mfma_kernel) + score_filter_wide_kernel
 out = {}
 for wl, kern in KERNEL.items():
     vals = {}

@@ -25,7 +25,8 @@ def main():
     shard = bench.build_shard(native, torch, 0, rows, dim, store, 0, [], queries, k)
     esize = 2 if store == "bf16" else 4
     out = {"rows": rows, "dim": dim, "store": store, "k": k, "points": []}
-    for b in (1, 2, 3, 4, 8, 9, 16, 32, 33, 64, 128, 256, 1024, 4096):
+    batches = [int(x) for x in os.environ.get("SWEEP_BATCHES", "1,2,3,4,8,9,16,32,33,64,128,256,512,1024,2048,4096").split(",")]
+    for b in batches:
         q = queries[:b].contiguous()
         for _ in range(3):
             shard.search_device(q, k=k)
