@@ -102,6 +102,8 @@ struct MfmaPlan {
     int grid;
     size_t lds;
     size_t cand_bytes;        // scratch for the workgroups' candidate buffers
+    int stream_rows;          // row tiles loaded with the streaming (nt) cache policy
+    int stages;               // LDS stage buffers: 2, or 3 (ring with counted waits)
 };
 
 // Launch shape of the matrix-core scoring kernel; -1 when the shape is not

@@ -56,7 +56,7 @@ constexpr int TM = 128;
 constexpr int kThreads = 256;
 constexpr int kStepBytes = 128;  // K bytes of a row per step: 64 bf16 or 32 fp32
 constexpr int stage_bytes(int tnq) { return (TM + tnq) * kStepBytes; }  // row tile then query tile
-constexpr int lds_bytes(int tnq) { return 2 * stage_bytes(tnq) + tnq * 12 + (kThreads / 64) * 1024; }
+constexpr int lds_bytes(int tnq, int stages) { return stages * stage_bytes(tnq) + tnq * 12 + (kThreads / 64) * 1024; }
 
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -231,7 +231,10 @@ __device__ __forceinline__ void compact_query(unsigned long long* buf, int c, in
 // One 32 x 32 MFMA tile of finished scores (one query per lane column, 16 rows
 // per lane: row0 + (r & 3) + 8 * (r >> 2) for register r): appends what is
 // above the query's threshold to its candidate buffer and clears the tile.
-template <int CAP>
+// WAIT_STORES: the wave waits for its stores before it goes on (the caller's
+// next barrier then makes them visible to the workgroup without draining the
+// loads of waves that stored nothing).
+template <int CAP, bool WAIT_STORES>
 __device__ __forceinline__ void append_above(f32x16& tile, float thr, int ql, long long row0, bool last_tile,
                                              const MfmaArgs& a, int* cnt_lds, unsigned long long* my_buf) {
     float mx = tile[0];
@@ -273,9 +276,17 @@ __device__ __forceinline__ void append_above(f32x16& tile, float thr, int ql, lo
                 }
             }
         }
+        if constexpr (WAIT_STORES) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) tile[r] = 0.f;
+}
+
+// s_barrier without the drain of outstanding loads that __syncthreads() adds.
+__device__ __forceinline__ void barrier_keeping_loads() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
 }
 
 // The calling wave looks after queries [q0, q0 + nq), nq <= 64: re-selects any
@@ -336,8 +347,16 @@ __device__ __forceinline__ void write_range_lists(int q0, int nq, int qt_base, i
 // MAX_ONLY: the sampling form, which keeps nothing but each query's best score
 // per tile (a.tile_max).  A compile-time switch: as a run-time branch it made
 // the compiler copy all accumulators after every K step.
-template <typename T, int CAP, int TNQ, bool MAX_ONLY>
+// ROW_AUX: cache-policy bits of the row-tile loads (2 = nt, streaming).
+// NS: LDS stage buffers.  2: the next step is requested before this step's
+// MFMAs and waited for at the step's barrier (which drains every load).  3: a
+// ring -- step s + 2 is requested as soon as the barrier of step s has shown
+// that everybody is done with step s - 1, waits are counted (loads return in
+// order, so "at most N outstanding" means all but the newest N have landed) and
+// the barriers leave loads in flight, so the memory pipeline never runs empty.
+template <typename T, int CAP, int TNQ, bool MAX_ONLY, int ROW_AUX, int NS>
 __global__ __launch_bounds__(kThreads, 2) void score_topk_mfma_kernel(MfmaArgs a) {
+    static_assert(NS == 2 || (NS == 3 && !MAX_ONLY), "the ring form exists for the full launch only");
     if (a.run_if && *a.run_if == 0) return;
     constexpr int TN = TNQ;
     constexpr int WAVES = kThreads / 64;
@@ -348,12 +367,11 @@ __global__ __launch_bounds__(kThreads, 2) void score_topk_mfma_kernel(MfmaArgs a
     constexpr int QPW = TNQ / WAVES;             // queries each wave looks after
     static_assert(CAP >= 2 * TM, "a tile may append TM keys per query on top of k + slack kept ones");
     constexpr int kStageBytes = stage_bytes(TNQ);
-    constexpr int ROW_AUX = 0;  // default cache policy for the row tiles (non-temporal measured 13-28 % slower)
     constexpr int BK = kStepBytes / (int)sizeof(T);
     static_assert((CAP & (CAP - 1)) == 0, "CAP must be a power of two");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const stage0 = smem;
-    float* floor_lds = reinterpret_cast<float*>(smem + 2 * kStageBytes);  // own k-th best score (strict)
+    float* floor_lds = reinterpret_cast<float*>(smem + NS * kStageBytes);  // own k-th best score (strict)
     int* cnt_lds = reinterpret_cast<int*>(floor_lds + TN);
     float* shared_lds = reinterpret_cast<float*>(cnt_lds + TN);           // best floor of ANY range (non-strict)
     unsigned int* hist_lds = reinterpret_cast<unsigned int*>(shared_lds + TN) + (threadIdx.x >> 6) * 256;
@@ -407,6 +425,65 @@ __global__ __launch_bounds__(kThreads, 2) void score_topk_mfma_kernel(MfmaArgs a
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
     const long long total_steps = my_tiles * ksteps;
+    if constexpr (NS == 3) {
+        constexpr int LPS = (TM + TNQ) / (8 * WAVES);  // load instructions per wave and step
+        long long ld_tile = tile_lo, ld_ptile = phys(tile_lo);
+        int ld_ks = 0, ld_stage = 0;
+        auto request_step = [&]() {
+            char* st = stage0 + ld_stage * kStageBytes;
+            stage_tile<ROW_AUX, TM, WAVES>(a.rows, ld_ptile * TM, a.n - 1, row_bytes, ld_ks * kStepBytes, st, wave, lane);
+            stage_tile<0, TNQ, WAVES>(qbase, 0, TN - 1, row_bytes, ld_ks * kStepBytes, st + TM * kStepBytes, wave, lane);
+            ld_stage = ld_stage == NS - 1 ? 0 : ld_stage + 1;
+            if (++ld_ks == ksteps) {
+                ld_ks = 0;
+                ++ld_tile;
+                ld_ptile = phys(ld_tile);
+            }
+        };
+        // The floors above were plain loads; nothing but tile requests may be in
+        // flight when the counted waits start.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (total_steps > 0) request_step();
+        if (total_steps > 1) request_step();
+        long long tile = tile_lo, ptile = phys(tile_lo);
+        int ks = 0, cur = 0;
+        for (long long s = 0; s < total_steps; ++s) {
+            // step s has landed (this wave's share; the barrier extends it to all)
+            if (s + 1 < total_steps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            barrier_keeping_loads();
+            // every wave is past the MFMAs of step s - 1: its buffer takes step s + 2
+            if (s + 2 < total_steps) request_step();
+            if (ks == 0 && tid < TN)
+                pending_floor = __hip_atomic_load(shared_floor + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const char* st = stage0 + cur * kStageBytes;
+            if (!(a.debug_no_candidates & 32)) mfma_step<MT, NT>(T{}, st, st + TM * kStepBytes, row_off, q_off, lane, acc);
+            cur = cur == NS - 1 ? 0 : cur + 1;
+            if (ks + 1 == ksteps) {
+                const long long row_base = ptile * TM + row_off + 4 * (lane >> 5);
+                const bool last_tile = (ptile + 1) * TM > a.n;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const int ql = q_off + n * 32 + (lane & 31);
+                    const float thr = fmaxf(floor_lds[ql], unorder_f32(order_f32(shared_lds[ql]) - 1u));
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+                        append_above<CAP, true>(acc[m][n], thr, ql, row_base + m * 32, last_tile, a, cnt_lds, my_buf);
+                }
+                barrier_keeping_loads();  // counts and keys of this tile are visible to the selecting waves
+                if (tid < TN) shared_lds[tid] = unorder_f32(pending_floor | (pending_floor == 0 ? 0x007fffffu : 0u));
+                reselect_where_full<CAP>(wave * QPW, QPW, TM, lane, a, floor_lds, cnt_lds, my_buf, shared_floor, hist_lds);
+                ks = 0;
+                ++tile;
+                ptile = phys(tile);
+            } else {
+                ++ks;
+            }
+        }
+        __syncthreads();
+        write_range_lists<CAP>(wave * QPW, QPW, qt * TN, range, lane, a, floor_lds, cnt_lds, my_buf, shared_floor, hist_lds);
+        return;
+    }
     if (total_steps > 0) {
         stage_tile<ROW_AUX, TM, WAVES>(a.rows, phys(tile_lo) * TM, a.n - 1, row_bytes, 0, stage0, wave, lane);
         stage_tile<0, TNQ, WAVES>(qbase, 0, TN - 1, row_bytes, 0, stage0 + TM * kStepBytes, wave, lane);
@@ -460,7 +537,7 @@ __global__ __launch_bounds__(kThreads, 2) void score_topk_mfma_kernel(MfmaArgs a
                 const float thr = fmaxf(floor_lds[ql], unorder_f32(order_f32(shared_lds[ql]) - 1u));
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
-                    append_above<CAP>(acc[m][n], thr, ql, row_base + m * 32, last_tile, a, cnt_lds, my_buf);
+                    append_above<CAP, false>(acc[m][n], thr, ql, row_base + m * 32, last_tile, a, cnt_lds, my_buf);
             }
         }
         __syncthreads();
@@ -518,11 +595,25 @@ int plan_mfma(int dtype, int64_t n, int ld, int b, int k, int num_cus, MfmaPlan*
     plan->tm = tm;
     const long long n_tiles = (n + tm - 1) / tm;
     plan->n_tiles = n_tiles;
+    // Row loads carry the streaming (nt) policy when every row byte is fetched
+    // once per launch -- a single query tile -- and the rows exceed the Infinity
+    // Cache: 16-byte direct-to-LDS loads then read 7.05 TB/s against 6.2 TB/s
+    // under the default policy (profiles/micro/tile_read_patterns.hip).  With
+    // several query tiles the later ones find the rows in L2, which streaming
+    // lines would leave first.
+    plan->stream_rows = (plan->n_qtiles == 1 && (double)n * ld * esize > 192.0 * 1024 * 1024) ? 1 : 0;
+    if (const char* e = getenv("MTR_MFMA_STREAM_ROWS")) plan->stream_rows = atoi(e) != 0;
+    // ... and, for the 32- and 64-query tiles of bf16 shards, the three-buffer
+    // ring (12.5M x 768 bf16, 64 queries: 3.16 -> 3.07 ms; 1M x 1024: 0.394 ->
+    // 0.375 ms; fp32 shards are bound by the fp32 matrix rate there and lose 1-2 %
+    // to the ring's two workgroups per CU).
+    plan->stages = (plan->stream_rows && plan->tnq <= 64 && dtype == 2) ? 3 : 2;
+    if (const char* e = getenv("MTR_MFMA_STAGES")) plan->stages = (atoi(e) == 3 && plan->tnq <= 64) ? 3 : 2;
     // Workgroups per CU (= row ranges x query tiles / CUs): more, shorter row
     // ranges cost more in top-k selection than they gain in bytes in flight.
-    // Measured best: 3 for the 32-query tile (four fit), 2 for the 64- and
-    // 128-query tiles.
-    long long per_cu = plan->tnq == 32 ? 3 : 2;
+    // Measured best with two buffers: 3 for the 32-query tile (four fit), 2 for
+    // the 64- and 128-query tiles.  Two ring workgroups fit a CU's LDS.
+    long long per_cu = plan->stages == 3 ? 2 : plan->tnq == 32 ? 3 : 2;
     if (const char* e = getenv("MTR_MFMA_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
     // rounded down: a grid a few workgroups above per_cu * CUs runs those in a second round
     long long ranges = per_cu * num_cus / plan->n_qtiles;
@@ -531,7 +622,7 @@ int plan_mfma(int dtype, int64_t n, int ld, int b, int k, int num_cus, MfmaPlan*
     plan->tiles_per_range = (n_tiles + ranges - 1) / ranges;
     plan->n_ranges = (int)((n_tiles + plan->tiles_per_range - 1) / plan->tiles_per_range);
     plan->grid = plan->n_qtiles * plan->n_ranges;
-    plan->lds = lds_bytes(plan->tnq);
+    plan->lds = lds_bytes(plan->tnq, plan->stages);
     plan->cand_bytes = (size_t)plan->grid * plan->tnq * plan->cap * 8;
     return 0;
 }
@@ -577,23 +668,40 @@ hipError_t launch_score_mfma(const void* rows, int dtype, int64_t n, int ld, con
         hipLaunchKernelGGL(kernel, dim3(plan.grid), dim3(kThreads), plan.lds, stream, a);
         return hipGetLastError();
     };
-#define MTR_MFMA_PICK(T)                                                                              \
+#define MTR_MFMA_PICK(T, AUX)                                                                         \
     if (a.tile_max != nullptr) switch (plan.tnq) {                                                    \
-        case 32: return launch(&score_topk_mfma_kernel<T, 256, 32, true>);                            \
-        case 64: return launch(&score_topk_mfma_kernel<T, 256, 64, true>);                            \
-        case 128: return launch(&score_topk_mfma_kernel<T, 256, 128, true>);                          \
+        case 32: return launch(&score_topk_mfma_kernel<T, 256, 32, true, 0, 2>);                      \
+        case 64: return launch(&score_topk_mfma_kernel<T, 256, 64, true, 0, 2>);                      \
+        case 128: return launch(&score_topk_mfma_kernel<T, 256, 128, true, 0, 2>);                    \
         default: return hipErrorInvalidValue;                                                         \
     }                                                                                                 \
     switch (plan.tnq + (plan.cap == 256 ? 0 : 1)) {                                                   \
-        case 32: return launch(&score_topk_mfma_kernel<T, 256, 32, false>);                           \
-        case 33: return launch(&score_topk_mfma_kernel<T, 512, 32, false>);                           \
-        case 64: return launch(&score_topk_mfma_kernel<T, 256, 64, false>);                           \
-        case 65: return launch(&score_topk_mfma_kernel<T, 512, 64, false>);                           \
-        case 128: return launch(&score_topk_mfma_kernel<T, 256, 128, false>);                         \
-        default: return launch(&score_topk_mfma_kernel<T, 512, 128, false>);                          \
+        case 32: return launch(&score_topk_mfma_kernel<T, 256, 32, false, AUX, 2>);                   \
+        case 33: return launch(&score_topk_mfma_kernel<T, 512, 32, false, AUX, 2>);                   \
+        case 64: return launch(&score_topk_mfma_kernel<T, 256, 64, false, AUX, 2>);                   \
+        case 65: return launch(&score_topk_mfma_kernel<T, 512, 64, false, AUX, 2>);                   \
+        case 128: return launch(&score_topk_mfma_kernel<T, 256, 128, false, AUX, 2>);                 \
+        default: return launch(&score_topk_mfma_kernel<T, 512, 128, false, AUX, 2>);                  \
     }
-    if (dtype == 0) { MTR_MFMA_PICK(float) }
-    MTR_MFMA_PICK(bf16_t)
+#define MTR_MFMA_PICK_RING(T)                                                                         \
+    switch (plan.tnq + (plan.cap == 256 ? 0 : 1)) {                                                   \
+        case 32: return launch(&score_topk_mfma_kernel<T, 256, 32, false, 2, 3>);                     \
+        case 33: return launch(&score_topk_mfma_kernel<T, 512, 32, false, 2, 3>);                     \
+        case 64: return launch(&score_topk_mfma_kernel<T, 256, 64, false, 2, 3>);                     \
+        case 65: return launch(&score_topk_mfma_kernel<T, 512, 64, false, 2, 3>);                     \
+        default: return hipErrorInvalidValue;                                                         \
+    }
+    if (plan.stages == 3 && a.tile_max == nullptr) {
+        if (dtype == 0) { MTR_MFMA_PICK_RING(float) }
+        MTR_MFMA_PICK_RING(bf16_t)
+    }
+    if (plan.stream_rows) {
+        if (dtype == 0) { MTR_MFMA_PICK(float, 2) }
+        MTR_MFMA_PICK(bf16_t, 2)
+    }
+    if (dtype == 0) { MTR_MFMA_PICK(float, 0) }
+    MTR_MFMA_PICK(bf16_t, 0)
+#undef MTR_MFMA_PICK_RING
 #undef MTR_MFMA_PICK
 }
 

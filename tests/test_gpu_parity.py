@@ -474,6 +474,40 @@ def _search_with_env(shard, queries, k, **env):
                 os.environ[name] = value
 
 
+@pytest.mark.parametrize("store,d", [("bf16", 256), ("bf16", 128), ("fp32", 192), ("fp32", 64)])
+@pytest.mark.parametrize("b", [2, 37, 64, 100])
+@pytest.mark.parametrize("stride", [0, 3])
+def test_streaming_ring_form_equals_two_buffer_form(native, store, d, b, stride):
+    """Single-query-tile searches of large shards load the rows with the
+    streaming cache policy and, for up to 64 queries, through a three-buffer LDS
+    ring with counted waits.  Forced here on a small shard: bit-identical to the
+    two-buffer form (same K order), ties, a ragged last tile and row widths of
+    two K steps included; with and without the sampling launch."""
+    rng = np.random.default_rng(1300 + b + d + stride)
+    n, k = 128 * 300 + 51, 24   # 301 row tiles: a sampling stride of 3 is honoured
+    corpus = rng.standard_normal((n, d)).astype(np.float32)
+    queries = rng.standard_normal((b, d)).astype(np.float32)
+    for row in (128 * 3 + 3, 128 * 40 + 9, n - 2):
+        corpus[row] = corpus[5]
+    queries[0] = corpus[5]
+    shard = native.DeviceShard.from_host(corpus, store_dtype=store)
+    base_i, base_s = _search_with_env(shard, queries, k, MTR_MFMA_SAMPLE_STRIDE=stride, MTR_MFMA_STREAM_ROWS=0, MTR_MFMA_STAGES=2)
+    nt_i, nt_s = _search_with_env(shard, queries, k, MTR_MFMA_SAMPLE_STRIDE=stride, MTR_MFMA_STREAM_ROWS=1, MTR_MFMA_STAGES=2)
+    ring_i, ring_s = _search_with_env(shard, queries, k, MTR_MFMA_SAMPLE_STRIDE=stride, MTR_MFMA_STREAM_ROWS=1, MTR_MFMA_STAGES=3)
+    assert (base_i == nt_i).all() and (base_s == nt_s).all()
+    assert (base_i == ring_i).all() and (base_s == ring_s).all()
+    assert ring_i[0, :4].tolist() == [5, 128 * 3 + 3, 128 * 40 + 9, n - 2]
+    check_topk(ring_i, ring_s, orc.scores(queries, corpus), k, 1e-6 if store == "fp32" else 2.0 ** -8)
+    # the ring on a shard of a single row tile, and of fewer tiles than workgroups
+    for rows in (100, 128 * 5):
+        small = native.DeviceShard.from_host(corpus[:rows], store_dtype=store)
+        a_i, a_s = _search_with_env(small, queries, k, MTR_MFMA_STREAM_ROWS=0, MTR_MFMA_STAGES=2)
+        r_i, r_s = _search_with_env(small, queries, k, MTR_MFMA_STREAM_ROWS=1, MTR_MFMA_STAGES=3)
+        assert (a_i == r_i).all() and (a_s == r_s).all()
+        small.close()
+    shard.close()
+
+
 @pytest.mark.parametrize("b", [3, 37, 256, 300])
 @pytest.mark.parametrize("stride", [2, 5])
 def test_wide_tile_kernel_equals_general_kernel(native, b, stride):
