@@ -7,5 +7,5 @@ echo "== $envs $*"
 env $envs timeout -k 10 150 python3 bench.py "$@" --no-cpu-baseline > gpurun_out/dbg_run.out 2> gpurun_out/dbg_run.err
 rc=$?
 [ $rc -ge 124 ] && { echo "bench run ended with $rc"; tail -3 gpurun_out/dbg_run.err; exit $rc; }
-python3 profiles/kms.py < gpurun_out/dbg_run.out
+python3 profiles/kms.py < gpurun_out/dbg_run.out || { tail -3 gpurun_out/dbg_run.err; }
 exit 0
