@@ -185,23 +185,35 @@ int enqueue_mfma(mtr_index* ix, const mtr::MfmaPlan& plan, const void* dev_queri
     // launch scores in a few tenths of a ms.
     const bool big = forced_sample_stride() >= 0 ||
                      (double)ix->n * ix->ld * dtype_size(ix->dtype) >= kMinTwoPassBytes;
-    const int stride = big ? sample_stride(ix->n, plan.n_tiles, k) : 0;
+    // Large batches on bf16 shards: the 256 x 256-tile kernel, first in its
+    // sampling form over every wstride-th of ITS tiles (floors and filtered
+    // scores are then the same arithmetic bit for bit), then as a filter that
+    // appends every score that reaches its query's floor (about k * wstride per
+    // query: the floor is the k-th largest of n_tiles / wstride tile maxima); the
+    // general kernel is enqueued behind it and runs only if a key list overflowed.
+    mtr::WidePlan wide, wide_samp;
+    int wstride = 0;
+    bool use_wide = false;
+    if (big && ix->dtype == MTR_BF16 && b >= wide_min_batch()) {
+        const long long wtiles = (ix->n + 255) / 256;
+        wstride = sample_stride(ix->n, wtiles, k);
+        if (wstride >= 2) {
+            const long long n_wsamp = (wtiles + wstride - 1) / wstride;
+            const int hits = (int)std::min<long long>(1 << 24, (long long)std::max(4 * k, 20) * wstride);
+            use_wide = n_wsamp <= mtr::kMaxSampleTiles &&
+                       mtr::plan_wide(ix->dtype, ix->n, ix->ld, b, k, hits, ix->num_cus, &wide) == 0 &&
+                       mtr::plan_wide(ix->dtype, n_wsamp * 256, ix->ld, b, k, 0, ix->num_cus, &wide_samp) == 0;
+        }
+    }
+    // Otherwise the general kernel samples for itself (the fallback behind the
+    // wide kernel starts without floors).
+    const int stride = (big && !use_wide) ? sample_stride(ix->n, plan.n_tiles, k) : 0;
     mtr::MfmaPlan samp = plan;
     if (stride >= 2) {
         const long long n_samp = (plan.n_tiles + stride - 1) / stride;
         if (mtr::plan_mfma(ix->dtype, n_samp * plan.tm, ix->ld, b, k, ix->num_cus, &samp) != 0)
             return fail(MTR_ERR_INVALID, "internal: no launch shape for the sampling launch");
     }
-    // Large batches on bf16 shards: the sampling launch's floors feed the
-    // 256 x 256-tile filter kernel, which appends every score that reaches its
-    // query's floor (about k * stride per query: the floor is the k-th largest of
-    // n_tiles / stride tile maxima); the general kernel is enqueued behind it and
-    // runs only if a key list overflowed.
-    mtr::WidePlan wide;
-    const bool use_wide =
-        stride >= 2 && ix->dtype == MTR_BF16 && b >= wide_min_batch() &&
-        mtr::plan_wide(ix->dtype, ix->n, ix->ld, b, k, (int)std::min<long long>(1 << 24, (long long)std::max(4 * k, 20) * stride),
-                       ix->num_cus, &wide) == 0;
     const size_t q_row_bytes = (size_t)ix->ld * dtype_size(ix->dtype);
     const int64_t q_rows = std::max<int64_t>((int64_t)plan.n_qtiles * plan.tnq, use_wide ? (int64_t)wide.n_qtiles * 256 : 0);
     const size_t qbytes = (size_t)q_rows * q_row_bytes;
@@ -211,14 +223,15 @@ int enqueue_mfma(mtr_index* ix, const mtr::MfmaPlan& plan, const void* dev_queri
     if ((rc = ix->mfma_cand.reserve(plan.cand_bytes)) != MTR_OK) return rc;
     if ((rc = ix->cand_s.reserve((size_t)b * plan.n_ranges * k * 4)) != MTR_OK) return rc;
     if ((rc = ix->cand_i.reserve((size_t)b * plan.n_ranges * k * 4)) != MTR_OK) return rc;
-    const int floor_words = plan.n_qtiles * plan.tnq;
+    const int floor_words = std::max(plan.n_qtiles * plan.tnq, use_wide ? wide.n_qtiles * 256 : 0);
     if ((rc = ix->mfma_floor.reserve((size_t)floor_words * 4)) != MTR_OK) return rc;
     if (use_wide) {
         if ((rc = ix->wide_keys.reserve(wide.key_bytes)) != MTR_OK) return rc;
         if ((rc = ix->wide_counts.reserve((wide.count_words + 1) * 4)) != MTR_OK) return rc;
+        if ((rc = ix->tile_max.reserve((size_t)wide.n_qtiles * 256 * wide_samp.n_tiles * 4)) != MTR_OK) return rc;
     }
     if (stride >= 2 && (rc = ix->tile_max.reserve((size_t)floor_words * samp.n_tiles * 4)) != MTR_OK) return rc;
-    // The sampling launch's floor kernel sets every real query's floor; otherwise they start from zero.
+    // A sampling launch's floor kernel sets every real query's floor; otherwise they start from zero.
     if (stride < 2) HIP_TRY(hipMemsetAsync(ix->mfma_floor.p, 0, (size_t)floor_words * 4, stream));
     // Query rows past b must be zero.  The buffer keeps its contents between
     // searches, so only rows never initialised, or holding an earlier, larger
@@ -261,12 +274,19 @@ int enqueue_mfma(mtr_index* ix, const mtr::MfmaPlan& plan, const void* dev_queri
     if (use_wide) {
         unsigned int* counts = static_cast<unsigned int*>(ix->wide_counts.p);
         unsigned long long* keys = static_cast<unsigned long long*>(ix->wide_keys.p);
+        unsigned int* tile_max = static_cast<unsigned int*>(ix->tile_max.p);
         overflow = reinterpret_cast<int*>(counts + wide.count_words);
         HIP_TRY(hipMemsetAsync(overflow, 0, 4, stream));
-        HIP_TRY(mtr::launch_score_wide(ix->rows, ix->n, ix->ld, ix->q_bf16.p, b, wide, floors, keys, counts, stream));
+        // the sampling form raises tile_max with atomic maxima: every word starts at zero (below any score)
+        HIP_TRY(hipMemsetAsync(tile_max, 0, (size_t)wide.n_qtiles * 256 * wide_samp.n_tiles * 4, stream));
+        HIP_TRY(mtr::launch_score_wide(ix->rows, ix->n, ix->ld, ix->q_bf16.p, b, wide_samp, nullptr, nullptr, nullptr, wstride,
+                                       tile_max, stream));
+        HIP_TRY(mtr::launch_floor_from_tile_max(tile_max, (int)wide_samp.n_tiles, b, k, floors, stream));
+        HIP_TRY(mtr::launch_score_wide(ix->rows, ix->n, ix->ld, ix->q_bf16.p, b, wide, floors, keys, counts, 1, nullptr, stream));
         if (ix->profiling) HIP_TRY(hipEventRecord(e1, stream));
         HIP_TRY(mtr::launch_select_keys(keys, counts, wide.n_lists * mtr::kWideSubs, mtr::kWideSubs, wide.cap, (int)ix->n, b, k, ix->row_offset, dev_out_idx,
                                         dev_out_score, overflow, stream));
+        HIP_TRY(mtr::launch_reset_floors_if(floors, floor_words, overflow, stream));
     }
     const mtr::MfmaPass all{1, nullptr, overflow};
     HIP_TRY(mtr::launch_score_mfma(ix->rows, ix->dtype, ix->n, ix->ld, ix->q_bf16.p, b, k, plan, all, ix->mfma_cand.p,

@@ -137,7 +137,7 @@ hipError_t launch_score_mfma(const void* rows, int dtype, int64_t n, int ld, con
 hipError_t launch_floor_from_tile_max(const unsigned int* tile_max, int n_tiles, int b, int k,
                                       unsigned int* shared_floor, hipStream_t stream);
 
-constexpr int kWideSubs = 4;  // key lists per (workgroup, query): one per lane that holds the query's scores
+constexpr int kWideSubs = 8;  // key lists per (workgroup, query): one per lane that holds the query's scores
 struct WidePlan {
     int n_qtiles;             // query tiles of 256
     int n_lists;              // interleaved row lists (workgroups per query tile)
@@ -154,15 +154,23 @@ struct WidePlan {
 // per query the given floors are expected to let through.
 int plan_wide(int dtype, int64_t n, int ld, int b, int k, int expected_hits, int num_cus, WidePlan* plan);
 
-// rows x queries on the matrix cores; every score >= its query's floor
-// (floors[q], order-preserving bits as written by launch_floor_from_tile_max)
-// is appended as  row | score bits << 32  to keys[query tile][list][query][sub][0..cap)
-// (rows past n in the last tile included, as copies of the last row), and
-// counts[...][sub] receives how many reached the floor (more than cap: the list
-// is incomplete).  queries: [n_qtiles*256][ld] bf16, rows past b zero.
+// rows x queries on the matrix cores.  tile_max NULL: every score >= its query's
+// floor (floors[q], order-preserving bits as written by
+// launch_floor_from_tile_max) is appended as  row | score bits << 32  to
+// keys[query tile][list][query][sub][0..cap) (rows past n in the last tile
+// included, as copies of the last row), and counts[...][sub] receives how many
+// reached the floor (more than cap: the list is incomplete).  tile_max not
+// NULL (sampling form): tile t of the launch is tile t * tile_stride of the
+// matrix, and tile_max[q][t] ([n_qtiles*256][plan.n_tiles], zeroed by the
+// caller) receives each query's best score of the tile.  plan: from plan_wide
+// for the rows the launch covers (its tiles x 256).
+// queries: [n_qtiles*256][ld] bf16, rows past b zero.
 hipError_t launch_score_wide(const void* rows, int64_t n, int ld, const void* queries, int b, const WidePlan& plan,
                              const unsigned int* floors, unsigned long long* keys, unsigned int* counts,
-                             hipStream_t stream);
+                             int tile_stride, unsigned int* tile_max, hipStream_t stream);
+
+// floors[0..words) = 0 when *flag != 0 (device word); nothing otherwise.
+hipError_t launch_reset_floors_if(unsigned int* floors, int words, const int* flag, hipStream_t stream);
 
 // The best k_out of each query's key lists written by launch_score_wide, in
 // (score descending, row ascending) order, ignoring keys of rows >= n_rows (the

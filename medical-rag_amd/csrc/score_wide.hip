@@ -15,12 +15,16 @@
 // k-th largest of the per-tile best scores of a sampling launch, which k
 // different rows reach, so no row below it can be among the k best -- and
 // appends every score that reaches the floor, as (row, score bits),
-// to a list private to the lane (four lanes of a workgroup hold a query's
-// scores: four lists per workgroup and query), counting in a register.  A
+// to a list private to the lane (eight lanes of a workgroup hold a query's
+// scores: eight lists per workgroup and query), counting in a register.  A
 // list that overflows keeps counting; the selection kernel that follows
 // (merge_topk.hip, launch_select_keys) sees the count, raises a flag, and the
 // caller's already enqueued launch of the general kernel, which does nothing
 // unless the flag is set, recomputes the batch.  Results are exact either way.
+// The floors come from this kernel's own sampling form (MAX_ONLY: every
+// stride-th row tile, only each query's best score per tile is kept), so that
+// floors and filtered scores are the same arithmetic to the last bit: the k
+// rows behind a floor reach it again in the full launch.
 //
 // Work split.  One workgroup per (query tile, row list); row list r of R holds
 // tiles r, r + R, r + 2R, ...: neighbouring rows are often about the same
@@ -28,8 +32,10 @@
 // over the lists, which is what sizes the buffers.
 //
 // Tile.  Waves 2 x 4: wave (wm, wn) owns rows [128 wm, +128) x queries
-// [64 wn, +64) as 4 x 2 MFMA tiles of 32 x 32 (v_mfma_f32_32x32x16_bf16), K
-// steps of 64 elements.  LDS holds two K steps, each as four half tiles of 128
+// [64 wn, +64) as 8 x 4 MFMA tiles of 16 x 16 (v_mfma_f32_16x16x32_bf16: the
+// same cycles per flop and LDS reads as 4 x 2 tiles of 32 x 32 x 16, but the
+// chip holds a higher clock under it -- 7.28 against 7.84 ms for the bare loop,
+// profiles/micro/mfma256_core.hip), K steps of 64 elements.  LDS holds two K steps, each as four half tiles of 128
 // rows x 128 bytes (rows 0-127, rows 128-255, queries 0-127, queries 128-255),
 // filled by 16-byte direct-to-LDS loads whose 16-byte chunks are XOR-swizzled
 // with the row number on the source address.  The two wave groups (wm = 0, 1)
@@ -72,7 +78,7 @@ constexpr int kWideStepBytes = 4 * kHalfBytes;  // rows lo, rows hi, queries lo,
 constexpr size_t kWideLds = 2 * kWideStepBytes;
 
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
-using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
@@ -83,7 +89,9 @@ struct WideArgs {
     const char* queries;      // [n_qtiles*256][ld] bf16, zero rows past b
     int b;
     int n_lists;              // row lists (workgroups per query tile)
-    long long n_tiles;
+    long long n_tiles;        // tiles this launch covers (numbered 0.. in its own order)
+    int tile_stride;          // tile t of the launch is tile t * tile_stride of the matrix
+    unsigned int* tile_max;   // sampling form: [n_qtiles*256][n_tiles] best score per (query, tile), zeroed by the caller
     const unsigned int* floor;    // [b] order-preserving score bits (0: no floor)
     unsigned long long* keys;     // [n_qtiles][n_lists][256][kWideSubs][cap]: row | (unsigned long long)score bits << 32
     unsigned int* counts;         // [n_qtiles][n_lists][256][kWideSubs] scores that reached the floor (may exceed cap)
@@ -132,6 +140,9 @@ __device__ __forceinline__ void barrier_keeping_loads() {
     asm volatile("" ::: "memory");
 }
 
+// MAX_ONLY: the sampling form (a.tile_max), which keeps nothing but each
+// query's best score per tile.
+template <bool MAX_ONLY>
 __global__ __launch_bounds__(kWideThreads, 2) void score_filter_wide_kernel(WideArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -155,20 +166,20 @@ __global__ __launch_bounds__(kWideThreads, 2) void score_filter_wide_kernel(Wide
     const char* qbase = a.queries + (size_t)qt * kWideTile * row_bytes;
     const long long total = my_tiles * ksteps;
 
-    // This lane's two queries (accumulator column = lane & 31) and their floors.
-    float thr[2];
+    // This lane's four queries (accumulator column = lane & 15) and their floors.
+    float thr[4];
 #pragma unroll
-    for (int nn = 0; nn < 2; ++nn) {
-        const int q = qt * kWideTile + wn * 64 + nn * 32 + (lane & 31);
+    for (int nn = 0; nn < 4; ++nn) {
+        const int q = qt * kWideTile + wn * 64 + nn * 16 + (lane & 15);
         thr[nn] = __builtin_huge_valf();  // padding queries collect nothing
-        if (q < a.b && !(a.debug & 1)) {
+        if (!MAX_ONLY && q < a.b && !(a.debug & 1)) {
             const unsigned int f = a.floor[q];
             thr[nn] = unorder_f32(f | (f == 0 ? 0x007fffffu : 0u));  // no floor: -inf
         }
     }
     // The floors must have arrived before the first tile load is requested: the
     // loop's counted waits assume that nothing else is in flight.
-    asm volatile("" ::"v"(thr[0]), "v"(thr[1]) : "memory");
+    asm volatile("" ::"v"(thr[0]), "v"(thr[1]), "v"(thr[2]), "v"(thr[3]) : "memory");
 
     // load cursor: the next K step to request
     long long ld_tile = tile_first;
@@ -176,20 +187,22 @@ __global__ __launch_bounds__(kWideThreads, 2) void score_filter_wide_kernel(Wide
     auto request_step = [&]() {
         char* dst = smem + ld_buf * kWideStepBytes;
         request_queries(qbase, row_bytes, ld_ks * 128, dst, wave, lane);
-        request_rows(a.rows, ld_tile * kWideTile + wm * 128, a.n - 1, row_bytes, ld_ks * 128, dst + wm * kHalfBytes, wn, lane);
+        request_rows(a.rows, ld_tile * a.tile_stride * kWideTile + wm * 128, a.n - 1, row_bytes, ld_ks * 128,
+                     dst + wm * kHalfBytes, wn, lane);
         ld_buf ^= 1;
         if (++ld_ks == ksteps) { ld_ks = 0; ld_tile += tile_step; }
     };
     if (total > 0) request_step();
     if (total > 1) request_step();
 
-    f32x16 acc[4][2];
+    // acc[m][nn]: rows 16 m + 4 (lane / 16) + r of the wave's 128, query 16 nn + lane % 16 of its 64
+    f32x4 acc[8][4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < 8; ++m)
 #pragma unroll
-        for (int nn = 0; nn < 2; ++nn)
+        for (int nn = 0; nn < 4; ++nn)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][nn][r] = 0.f;
+            for (int r = 0; r < 4; ++r) acc[m][nn][r] = 0.f;
 
     // step 0 has landed for everybody; then group 1 falls one barrier behind
     if (total > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -197,12 +210,12 @@ __global__ __launch_bounds__(kWideThreads, 2) void score_filter_wide_kernel(Wide
     barrier_keeping_loads();
     if (wm == 1) barrier_keeping_loads();
 
-    // Each query's scores of a tile sit in four lanes of the workgroup (wm = 0, 1 x
-    // lane / 32 = 0, 1); each of them appends to a list of its own and counts in a
+    // Each query's scores of a tile sit in eight lanes of the workgroup (wm = 0, 1 x
+    // lane / 16 = 0..3); each of them appends to a list of its own and counts in a
     // register.
-    const int sub = wm * 2 + (lane >> 5);
+    const int sub = wm * 4 + (lane >> 4);
     unsigned long long* my_keys = a.keys + ((size_t)wgid * kWideTile * kWideSubs + sub) * a.cap;
-    int cnt[2] = {0, 0};
+    int cnt[4] = {0, 0, 0, 0};
     const int cap_mask = a.cap - 1;  // cap is a power of two
     long long tile = tile_first;
     int ks = 0;
@@ -217,29 +230,30 @@ __global__ __launch_bounds__(kWideThreads, 2) void score_filter_wide_kernel(Wide
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         barrier_keeping_loads();                                   // first barrier of the step
-        bf16x8 fb[2][4], fa[2][4];
+        // Fragment of a 16 x 32 block: lane l holds elements 8 (l / 16) .. +7 of row l % 16.
+        bf16x8 fb[4][2], fa[4][2];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int nn = 0; nn < 2; ++nn) fb[nn][kk] = read_frag(sb, qrow + nn * 32 + (lane & 31), 2 * kk + (lane >> 5));
+            for (int nn = 0; nn < 4; ++nn) fb[nn][kk] = read_frag(sb, qrow + nn * 16 + (lane & 15), 4 * kk + (lane >> 4));
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int m = 0; m < 2; ++m) fa[m][kk] = read_frag(sa, m * 32 + (lane & 31), 2 * kk + (lane >> 5));
+            for (int m = 0; m < 4; ++m) fa[m][kk] = read_frag(sa, m * 16 + (lane & 15), 4 * kk + (lane >> 4));
         barrier_keeping_loads();                                   // second barrier
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < 4; ++m)
 #pragma unroll
-                for (int nn = 0; nn < 2; ++nn)
-                    acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m][kk], fb[nn][kk], acc[m][nn], 0, 0, 0);
+                for (int nn = 0; nn < 4; ++nn)
+                    acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m][kk], fb[nn][kk], acc[m][nn], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int m = 0; m < 2; ++m) fa[m][kk] = read_frag(sa, 64 + m * 32 + (lane & 31), 2 * kk + (lane >> 5));
+            for (int m = 0; m < 4; ++m) fa[m][kk] = read_frag(sa, 64 + m * 16 + (lane & 15), 4 * kk + (lane >> 4));
         // the queries of step s + 1: the older four of the eight loads in flight
         if (s + 1 < total) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         barrier_keeping_loads();                                   // third barrier
@@ -250,59 +264,77 @@ __global__ __launch_bounds__(kWideThreads, 2) void score_filter_wide_kernel(Wide
         if (!tile_done && s + 2 < total) request_step();
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < 4; ++m)
 #pragma unroll
-                for (int nn = 0; nn < 2; ++nn)
-                    acc[2 + m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m][kk], fb[nn][kk], acc[2 + m][nn], 0, 0, 0);
+                for (int nn = 0; nn < 4; ++nn)
+                    acc[4 + m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m][kk], fb[nn][kk], acc[4 + m][nn], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
 
-        if (ks + 1 == ksteps) {
-            // The tile's scores are complete.  Accumulator register r of MFMA tile m
-            // holds row 32 m + 8 (r / 4) + 4 (lane / 32) + r % 4 of the wave's 128.
-            // Rows past the end of the matrix (copies of the last row, in the last tile
-            // only) are appended like any other; the selection kernel drops them.
-            const int row_base = (int)(tile * kWideTile) + wm * 128 + 4 * (lane >> 5);
-            if (a.debug & 4) {
+        if (tile_done) {
+            // The tile's scores are complete.  Rows past the end of the matrix (copies
+            // of the last row, in the last tile only) are treated like any other: they
+            // cannot raise a maximum, and the selection kernel drops their keys.
+            const long long ptile = tile * a.tile_stride;
+            if constexpr (MAX_ONLY) {
 #pragma unroll
-                for (int nn = 0; nn < 2; ++nn)
+                for (int nn = 0; nn < 4; ++nn) {
+                    float mx = -__builtin_huge_valf();
 #pragma unroll
-                    for (int m = 0; m < 4; ++m)
+                    for (int m = 0; m < 8; ++m)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[m][nn][r] = 0.f;
-            } else
+                        for (int r = 0; r < 4; ++r) {
+                            mx = fmaxf(mx, acc[m][nn][r]);
+                            acc[m][nn][r] = 0.f;
+                        }
+                    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                    if (lane < 16)
+                        atomicMax(a.tile_max + ((size_t)qt * kWideTile + wn * 64 + nn * 16 + lane) * a.n_tiles + tile, order_f32(mx));
+                }
+            } else {
+                const int row_base = (int)(ptile * kWideTile) + wm * 128 + 4 * (lane >> 4);
+                if (a.debug & 4) {
 #pragma unroll
-            for (int nn = 0; nn < 2; ++nn) {
-                const int ql = wn * 64 + nn * 32 + (lane & 31);
-                unsigned long long* qkeys = my_keys + (size_t)ql * kWideSubs * a.cap;
-                // Three scores per test (v_max3): a branch costs more than the compare,
-                // and with some thousand scores per query reaching the floor, about one
-                // group in three holds one in some lane.
+                    for (int nn = 0; nn < 4; ++nn)
 #pragma unroll
-                for (int g = 0; g < 64; g += 3) {
-                    float mx = acc[g >> 4][nn][g & 15];
+                        for (int m = 0; m < 8; ++m)
 #pragma unroll
-                    for (int j = g + 1; j < g + 3 && j < 64; ++j) mx = fmaxf(mx, acc[j >> 4][nn][j & 15]);
-                    if (__builtin_expect(mx >= thr[nn], 0)) {
+                            for (int r = 0; r < 4; ++r) acc[m][nn][r] = 0.f;
+                } else
 #pragma unroll
-                        for (int j = g; j < g + 3 && j < 64; ++j) {
-                            const float v = acc[j >> 4][nn][j & 15];
-                            if (v >= thr[nn]) {
-                                // (raw score bits, row), wrapping around in a full list: the count
-                                // tells the selection kernel that the list is incomplete.
-                                using u32x2 = __attribute__((ext_vector_type(2))) unsigned int;
-                                *reinterpret_cast<u32x2*>(qkeys + (cnt[nn] & cap_mask)) =
-                                    u32x2{(unsigned int)(row_base + (j >> 4) * 32 + ((j & 15) >> 2) * 8 + (j & 3)), __float_as_uint(v)};
-                                ++cnt[nn];
+                for (int nn = 0; nn < 4; ++nn) {
+                    const int ql = wn * 64 + nn * 16 + (lane & 15);
+                    unsigned long long* qkeys = my_keys + (size_t)ql * kWideSubs * a.cap;
+                    // Three scores per test (v_max3): a branch costs more than the compare,
+                    // and with some thousand scores per query reaching the floor, about one
+                    // group in three holds one in some lane.
+#pragma unroll
+                    for (int g = 0; g < 32; g += 3) {
+                        float mx = acc[g >> 2][nn][g & 3];
+#pragma unroll
+                        for (int j = g + 1; j < g + 3 && j < 32; ++j) mx = fmaxf(mx, acc[j >> 2][nn][j & 3]);
+                        if (__builtin_expect(mx >= thr[nn], 0)) {
+#pragma unroll
+                            for (int j = g; j < g + 3 && j < 32; ++j) {
+                                const float v = acc[j >> 2][nn][j & 3];
+                                if (v >= thr[nn]) {
+                                    // (row, raw score bits), wrapping around in a full list: the count
+                                    // tells the selection kernel that the list is incomplete.
+                                    using u32x2 = __attribute__((ext_vector_type(2))) unsigned int;
+                                    *reinterpret_cast<u32x2*>(qkeys + (cnt[nn] & cap_mask)) =
+                                        u32x2{(unsigned int)(row_base + (j >> 2) * 16 + (j & 3)), __float_as_uint(v)};
+                                    ++cnt[nn];
+                                }
                             }
                         }
                     }
+#pragma unroll
+                    for (int m = 0; m < 8; ++m)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[m][nn][r] = 0.f;
                 }
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[m][nn][r] = 0.f;
             }
             if (s + 2 < total) request_step();
             ks = 0;
@@ -312,11 +344,21 @@ __global__ __launch_bounds__(kWideThreads, 2) void score_filter_wide_kernel(Wide
         }
     }
     if (wm == 0) barrier_keeping_loads();   // group 0 catches up with group 1's last barrier
+    if constexpr (!MAX_ONLY) {
 #pragma unroll
-    for (int nn = 0; nn < 2; ++nn) {
-        const int ql = wn * 64 + nn * 32 + (lane & 31);
-        a.counts[((size_t)wgid * kWideTile + ql) * kWideSubs + sub] = (unsigned int)cnt[nn];
+        for (int nn = 0; nn < 4; ++nn) {
+            const int ql = wn * 64 + nn * 16 + (lane & 15);
+            a.counts[((size_t)wgid * kWideTile + ql) * kWideSubs + sub] = (unsigned int)cnt[nn];
+        }
     }
+}
+
+// Every floor back to "none" when *flag is set: the general kernel that then
+// recomputes the batch is a different instruction mix, whose k-th best scores
+// may sit an ulp below floors derived from this kernel's arithmetic.
+__global__ void reset_floors_if_kernel(unsigned int* floors, int words, const int* flag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (*flag != 0 && i < words) floors[i] = 0u;
 }
 
 }  // namespace
@@ -347,7 +389,7 @@ int plan_wide(int dtype, int64_t n, int ld, int b, int k, int expected_hits, int
 
 hipError_t launch_score_wide(const void* rows, int64_t n, int ld, const void* queries, int b, const WidePlan& plan,
                              const unsigned int* floors, unsigned long long* keys, unsigned int* counts,
-                             hipStream_t stream) {
+                             int tile_stride, unsigned int* tile_max, hipStream_t stream) {
     WideArgs a;
     a.rows = static_cast<const char*>(rows);
     a.n = n;
@@ -356,15 +398,29 @@ hipError_t launch_score_wide(const void* rows, int64_t n, int ld, const void* qu
     a.b = b;
     a.n_lists = plan.n_lists;
     a.n_tiles = plan.n_tiles;
+    a.tile_stride = tile_stride < 1 ? 1 : tile_stride;
+    a.tile_max = tile_max;
     a.floor = floors;
     a.keys = keys;
     a.counts = counts;
     a.cap = plan.cap;
     a.debug = getenv("MTR_WIDE_DEBUG") ? atoi(getenv("MTR_WIDE_DEBUG")) : 0;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(score_filter_wide_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(score_filter_wide_kernel, dim3(plan.grid), dim3(kWideThreads), plan.lds, stream, a);
+    // the last tile of the launch must exist in the matrix
+    if ((plan.n_tiles - 1) * a.tile_stride * kWideTile >= n) return hipErrorInvalidValue;
+    auto launch = [&](auto kernel) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kernel, dim3(plan.grid), dim3(kWideThreads), plan.lds, stream, a);
+        return hipGetLastError();
+    };
+    if (tile_max != nullptr) return launch(&score_filter_wide_kernel<true>);
+    return launch(&score_filter_wide_kernel<false>);
+}
+
+hipError_t launch_reset_floors_if(unsigned int* floors, int words, const int* flag, hipStream_t stream) {
+    if (words < 1) return hipSuccess;
+    hipLaunchKernelGGL(reset_floors_if_kernel, dim3((words + 255) / 256), dim3(256), 0, stream, floors, words, flag);
     return hipGetLastError();
 }
 
