@@ -140,6 +140,20 @@ __device__ __forceinline__ void barrier_keeping_loads() {
     asm volatile("" ::: "memory");
 }
 
+// The 64-row x 64-query half of a wave's tile, one K step: 4 x 4 tiles of 16 x 16,
+// two K blocks of 32.  FIRST: the sums start from zero instead of acc.
+template <bool FIRST>
+__device__ __forceinline__ void mfma_half(const bf16x8 (&fa)[4][2], const bf16x8 (&fb)[4][2], f32x4 (&acc)[8][4], int m0) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int nn = 0; nn < 4; ++nn) {
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            f32x4 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m][0], fb[nn][0], FIRST ? zero : acc[m0 + m][nn], 0, 0, 0);
+            acc[m0 + m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m][1], fb[nn][1], c, 0, 0, 0);
+        }
+}
+
 // MAX_ONLY: the sampling form (a.tile_max), which keeps nothing but each
 // query's best score per tile.
 template <bool MAX_ONLY>
@@ -202,7 +216,7 @@ __global__ __launch_bounds__(kWideThreads, 2) void score_filter_wide_kernel(Wide
 #pragma unroll
         for (int nn = 0; nn < 4; ++nn)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[m][nn][r] = 0.f;
+            for (int r = 0; r < 4; ++r) acc[m][nn][r] = 0.f;   // (every tile's first K step overwrites them)
 
     // step 0 has landed for everybody; then group 1 falls one barrier behind
     if (total > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -241,14 +255,12 @@ __global__ __launch_bounds__(kWideThreads, 2) void score_filter_wide_kernel(Wide
 #pragma unroll
             for (int m = 0; m < 4; ++m) fa[m][kk] = read_frag(sa, m * 16 + (lane & 15), 4 * kk + (lane >> 4));
         barrier_keeping_loads();                                   // second barrier
+        // A tile's first K step starts its sums from the constant zero, which
+        // spares the epilogue 128 register clears per tile.
+        const bool first = ks == 0;
         __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int nn = 0; nn < 4; ++nn)
-                    acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m][kk], fb[nn][kk], acc[m][nn], 0, 0, 0);
+        if (first) mfma_half<true>(fa, fb, acc, 0);
+        else mfma_half<false>(fa, fb, acc, 0);
         __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
@@ -263,13 +275,8 @@ __global__ __launch_bounds__(kWideThreads, 2) void score_filter_wide_kernel(Wide
         const bool tile_done = ks + 1 == ksteps;
         if (!tile_done && s + 2 < total) request_step();
         __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int nn = 0; nn < 4; ++nn)
-                    acc[4 + m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m][kk], fb[nn][kk], acc[4 + m][nn], 0, 0, 0);
+        if (first) mfma_half<true>(fa, fb, acc, 4);
+        else mfma_half<false>(fa, fb, acc, 4);
         __builtin_amdgcn_s_setprio(0);
 
         if (tile_done) {
@@ -284,10 +291,7 @@ __global__ __launch_bounds__(kWideThreads, 2) void score_filter_wide_kernel(Wide
 #pragma unroll
                     for (int m = 0; m < 8; ++m)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            mx = fmaxf(mx, acc[m][nn][r]);
-                            acc[m][nn][r] = 0.f;
-                        }
+                        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, acc[m][nn][r]);
                     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
                     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
                     if (lane < 16)
@@ -295,14 +299,7 @@ __global__ __launch_bounds__(kWideThreads, 2) void score_filter_wide_kernel(Wide
                 }
             } else {
                 const int row_base = (int)(ptile * kWideTile) + wm * 128 + 4 * (lane >> 4);
-                if (a.debug & 4) {
-#pragma unroll
-                    for (int nn = 0; nn < 4; ++nn)
-#pragma unroll
-                        for (int m = 0; m < 8; ++m)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) acc[m][nn][r] = 0.f;
-                } else
+                if (!(a.debug & 4))
 #pragma unroll
                 for (int nn = 0; nn < 4; ++nn) {
                     const int ql = wn * 64 + nn * 16 + (lane & 15);
@@ -330,10 +327,6 @@ __global__ __launch_bounds__(kWideThreads, 2) void score_filter_wide_kernel(Wide
                             }
                         }
                     }
-#pragma unroll
-                    for (int m = 0; m < 8; ++m)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[m][nn][r] = 0.f;
                 }
             }
             if (s + 2 < total) request_step();
