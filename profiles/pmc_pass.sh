@@ -10,4 +10,5 @@ timeout -s KILL 300 rocprofv3 --pmc $counters --output-format csv -d "$out" -- p
 csv=$(find "$out" -name "*counter_collection.csv" | head -1)
 [ -n "$csv" ] || { echo "no counter file"; tail -5 "$out.out"; exit 1; }
 python3 profiles/pmc_summary.py "$csv" "$kern" | tee "gpurun_out/pmc/${tag}.json"
+rm -rf "$out"   # the raw counter dump is large; only the summary travels back
 echo
