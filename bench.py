@@ -9,7 +9,7 @@ by torch.distributed.run, one rank per GPU) the corpus is row-sharded over the
 ranks (total size fixed: strong scaling) and each step ends with the RCCL
 all-gather of the per-rank candidates and the k-way merge.
 
-Workloads (BASELINE.json configs):
+Workloads:
     c4  10M x 1024 bf16, B=1, top-10   (default: the north-star headline shape)
     c2   1M x  768 fp32, B=1, top-10   (HBM-bound GEMV regime)
     c3   1M x 1024 bf16, B=4096, top-100 (matrix-core regime)

@@ -508,6 +508,33 @@ def test_streaming_ring_form_equals_two_buffer_form(native, store, d, b, stride)
     shard.close()
 
 
+@pytest.mark.parametrize("store", ["bf16", "fp32"])
+def test_forced_kernel_forms_are_exact_on_random_integer_shapes(native, store):
+    """Random shapes (ragged row counts, fewer rows than a tile, k above n, all
+    tile widths) with the large-shard forms forced on: streaming row loads, the
+    three-buffer ring, the sampling launch and, for bf16, the 256 x 256-tile
+    kernel.  Integer data under the inner-product metric: ids and scores must
+    equal the oracle bit for bit, ties everywhere."""
+    rng = np.random.default_rng(4242 if store == "bf16" else 4343)
+    for case in range(36):
+        n = int(rng.choice([1, 5, 127, 128, 129, 255, 257, 1000, 4097, 20000, 60001]))
+        d = int(rng.choice([64, 128, 192, 256, 320]))
+        b = int(rng.choice([2, 3, 31, 32, 33, 64, 65, 128, 129, 300]))
+        k = int(rng.choice([1, 5, 10, 33, 100, 256]))
+        stride = int(rng.choice([0, 2, 7]))
+        env = dict(MTR_MFMA_STREAM_ROWS=1, MTR_MFMA_STAGES=int(rng.choice([2, 3])), MTR_MFMA_SAMPLE_STRIDE=stride)
+        if store == "bf16" and case % 2 == 0:
+            env["MTR_WIDE_MIN_BATCH"] = 1
+        corpus = rng.integers(-3, 4, size=(n, d)).astype(np.float32)
+        queries = rng.integers(-3, 4, size=(b, d)).astype(np.float32)
+        shard = native.DeviceShard.from_host(corpus, store_dtype=store, normalize=False)
+        idx, score = _search_with_env(shard, queries, k, metric="ip", **env)
+        want_i, want_s = orc.search(queries, corpus, k, metric="ip")
+        assert (idx == want_i).all(), (case, n, d, b, k, env)
+        assert (score == want_s.astype(np.float32)).all(), (case, n, d, b, k, env)
+        shard.close()
+
+
 @pytest.mark.parametrize("b", [3, 37, 256, 300])
 @pytest.mark.parametrize("stride", [2, 5])
 def test_wide_tile_kernel_equals_general_kernel(native, b, stride):
