@@ -6,7 +6,9 @@
 // to merge the per-GPU lists.  The reference's counterpart is the single
 // np.argmax at pipeline/utils/local_rag.py:78.
 //
-// One workgroup per query, two kernels.  merge_select_kernel (32-bit local row
+// One workgroup per query, three kernels.  merge_heads_kernel (few short sorted
+// lists with 32-bit ids, k <= 32: what the row scan leaves) takes the k-th
+// largest list head as a floor and ranks the few keys that reach it.  merge_select_kernel (32-bit local row
 // ids, k <= 256: the per-workgroup and per-range lists of one shard) selects
 // the k-th largest packed key of each wave's slice with a radix walk and folds
 // the survivors; it does not need sorted input.  merge_topk_kernel (64-bit ids
@@ -350,7 +352,99 @@ __global__ void merge_select_kernel(MergeArgs a) {
     }
 }
 
+// Few short SORTED lists (the row scan's per-workgroup lists, best first), by
+// counting instead of selecting: the k-th largest list HEAD is a floor for the
+// k-th best overall, only the k lists whose heads reach it can hold anything
+// above it (at most k * k_in keys), and those survivors are ordered by rank.
+// Ranks come from LDS broadcast reads; there is no cross-lane dependency chain.
+constexpr int kHeadsThreads = 256;
+__global__ __launch_bounds__(kHeadsThreads) void merge_heads_kernel(MergeArgs a) {
+    if (a.run_if && *a.run_if == 0) return;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int total = a.n_lists * a.k_in;
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);  // [n_lists][k_in], 0 = empty
+    unsigned long long* surv = keys + total;                                   // [k_out * k_in]
+    unsigned long long* floor_lds = surv + (size_t)a.k_out * a.k_in;
+    int* count_lds = reinterpret_cast<int*>(floor_lds + 1);
+    const int tid = threadIdx.x;
+    const int q = blockIdx.x;
+    const long long qbase = (long long)q * a.query_stride;
+    // All of a thread's loads are issued before the first is used: taken one at
+    // a time they cost a memory round trip each, which was most of the kernel.
+    constexpr int kBatch = 8;
+    for (int i0 = tid; i0 < total; i0 += kHeadsThreads * kBatch) {
+        int id[kBatch];
+        float sc[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const int i = i0 + u * kHeadsThreads;
+            const int ic = i < total ? i : 0;
+            const int l = ic / a.k_in, j = ic - l * a.k_in;
+            id[u] = a.ci32[l * a.list_stride + qbase + j];
+            sc[u] = a.cs[l * a.list_stride_s + qbase + j];
+        }
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const int i = i0 + u * kHeadsThreads;
+            if (i < total) keys[i] = id[u] >= 0 ? pack_key(sc[u], id[u]) : 0ull;
+        }
+    }
+    if (tid == 0) {
+        floor_lds[0] = 0ull;   // fewer than k_out non-empty lists: everything survives
+        count_lds[0] = 0;
+    }
+    __syncthreads();
+    // The head that k_out - 1 other heads beat is the floor (heads are unique or empty).
+    for (int l = tid; l < a.n_lists; l += kHeadsThreads) {
+        const unsigned long long mine = keys[(size_t)l * a.k_in];
+        if (mine == 0ull) continue;
+        int rank = 0;
+        for (int o = 0; o < a.n_lists; ++o) rank += keys[(size_t)o * a.k_in] > mine ? 1 : 0;
+        if (rank == a.k_out - 1) floor_lds[0] = mine;
+    }
+    __syncthreads();
+    const unsigned long long floor = floor_lds[0];
+    for (int l = tid; l < a.n_lists; l += kHeadsThreads) {
+        for (int j = 0; j < a.k_in; ++j) {
+            const unsigned long long key = keys[(size_t)l * a.k_in + j];
+            if (key == 0ull || key < floor) break;   // sorted: nothing further down the list reaches the floor
+            surv[atomicAdd(&count_lds[0], 1)] = key;
+        }
+    }
+    __syncthreads();
+    const int c = count_lds[0];
+    float* os = a.out_s + (size_t)q * a.k_out;
+    long long* oi = a.out_i + (size_t)q * a.k_out;
+    for (int i = tid; i < c; i += kHeadsThreads) {
+        const unsigned long long mine = surv[i];
+        int rank = 0;
+        for (int o = 0; o < c; ++o) rank += surv[o] > mine ? 1 : 0;
+        if (rank < a.k_out) {
+            os[rank] = key_score(mine);
+            oi[rank] = (long long)key_row(mine) + a.idx_offset;
+        }
+    }
+    for (int i = c + tid; i < a.k_out; i += kHeadsThreads) {
+        os[i] = -__builtin_huge_valf();
+        oi[i] = -1ll;
+    }
+}
+
 }  // namespace
+
+hipError_t launch_merge_sorted_lists(const float* cand_s, const int* idx32, int n_lists, long long list_stride,
+                                     long long query_stride, int k_in, int b, int k_out, long long idx_offset,
+                                     long long* out_idx, float* out_score, hipStream_t stream) {
+    const size_t lds = ((size_t)n_lists * k_in + (size_t)k_out * k_in + 1) * 8 + 16;
+    if (k_out > 32 || k_in > 32 || n_lists > 1024 || lds > 48 * 1024)  // long merges: the selection kernel scales better
+        return launch_merge_topk(cand_s, idx32, nullptr, n_lists, list_stride, list_stride, query_stride, k_in, b, k_out,
+                                 idx_offset, out_idx, out_score, stream, nullptr);
+    if (b < 1 || k_out < 1 || k_in < 1 || n_lists < 1) return hipErrorInvalidValue;
+    MergeArgs a{cand_s, idx32, nullptr, n_lists, list_stride, list_stride, query_stride, k_in, k_out, idx_offset, out_idx, out_score,
+                0, nullptr, nullptr, 1, nullptr, 0, nullptr};
+    hipLaunchKernelGGL(merge_heads_kernel, dim3(b), dim3(kHeadsThreads), lds, stream, a);
+    return hipGetLastError();
+}
 
 hipError_t launch_merge_topk(const float* cand_s, const int* idx32, const long long* idx64, int n_lists,
                              long long list_stride, long long list_stride_s, long long query_stride, int k_in, int b, int k_out,

@@ -345,10 +345,10 @@ int enqueue_search(mtr_index* ix, const void* dev_queries, int q_dtype, int b, i
                                       metric == MTR_COSINE ? 1 : 0, ix->flag, k, plan, static_cast<float*>(ix->cand_s.p), static_cast<int*>(ix->cand_i.p),
                                       stream));
         if (ix->profiling) HIP_TRY(hipEventRecord(e1, stream));
-        HIP_TRY(mtr::launch_merge_topk(static_cast<const float*>(ix->cand_s.p), static_cast<const int*>(ix->cand_i.p),
-                                       nullptr, plan.grid, (long long)k, (long long)k, (long long)plan.grid * k, k, nb, k,
-                                       ix->row_offset, dev_out_idx + (size_t)b0 * k, dev_out_score + (size_t)b0 * k,
-                                       stream));
+        // the scan's per-workgroup lists are sorted best first
+        HIP_TRY(mtr::launch_merge_sorted_lists(static_cast<const float*>(ix->cand_s.p), static_cast<const int*>(ix->cand_i.p),
+                                               plan.grid, (long long)k, (long long)plan.grid * k, k, nb, k, ix->row_offset,
+                                               dev_out_idx + (size_t)b0 * k, dev_out_score + (size_t)b0 * k, stream));
     }
     return MTR_OK;
 }

@@ -172,6 +172,15 @@ hipError_t launch_score_wide(const void* rows, int64_t n, int ld, const void* qu
 // floors[0..words) = 0 when *flag != 0 (device word); nothing otherwise.
 hipError_t launch_reset_floors_if(unsigned int* floors, int words, const int* flag, hipStream_t stream);
 
+// The same for lists that are each sorted best first (score descending, row
+// ascending; short lists padded with id -1 at the end), 32-bit ids: by the
+// floor-from-the-heads kernel when the shape is small (k <= 32, all keys in 48 KB),
+// through launch_merge_topk otherwise.  Lists of a query are list_stride
+// elements apart in both arrays.
+hipError_t launch_merge_sorted_lists(const float* cand_s, const int* idx32, int n_lists, long long list_stride,
+                                     long long query_stride, int k_in, int b, int k_out, long long idx_offset,
+                                     long long* out_idx, float* out_score, hipStream_t stream);
+
 // The best k_out of each query's key lists written by launch_score_wide, in
 // (score descending, row ascending) order, ignoring keys of rows >= n_rows (the
 // last tile's padding); *overflow is set to 1 when a list of any query was
