@@ -46,10 +46,25 @@ __global__ __launch_bounds__(256) void load_rows_kernel(const SrcT* __restrict__
         const SrcT* s = src + row * d;
         double ss = 0.0;
         bool bad = false;
-        for (int e = lane; e < d; e += 64) {
-            const double x = to_f64<SrcT>(s[e]);
-            bad |= !(fabs(x) <= DBL_MAX);  // NaN or infinity
-            ss += x * x;
+        // A lane's loads go out kBatch at a time and are summed in element order
+        // afterwards (one at a time they cost a memory round trip each: 33 us for
+        // 34 query rows of 4096, most of a small search).
+        constexpr int kBatch = 16;
+        for (int e0 = lane; e0 < d; e0 += 64 * kBatch) {
+            SrcT v[kBatch];
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u) {
+                const int e = e0 + 64 * u;
+                v[u] = s[e < d ? e : lane];   // lane < d whenever this loop runs
+            }
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u) {
+                if (e0 + 64 * u < d) {
+                    const double x = to_f64<SrcT>(v[u]);
+                    bad |= !(fabs(x) <= DBL_MAX);  // NaN or infinity
+                    ss += x * x;
+                }
+            }
         }
         if (__ballot(bad) != 0ull) {
             if (lane == 0) atomicOr(nonfinite_flag, 1);
@@ -61,13 +76,25 @@ __global__ __launch_bounds__(256) void load_rows_kernel(const SrcT* __restrict__
             inv = norm;
         }
         DstT* o = dst + row * ld;
-        for (int e = lane; e < ld; e += 64) {
-            float v = 0.f;
-            if (e < d) {
-                const double x = to_f64<SrcT>(s[e]);
-                v = (float)(normalize ? x / inv : x);
+        for (int e0 = lane; e0 < ld; e0 += 64 * kBatch) {
+            SrcT v[kBatch];
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u) {
+                const int e = e0 + 64 * u;
+                v[u] = s[e < d ? e : 0];   // d >= 1
             }
-            o[e] = from_f32<DstT>(v);
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u) {
+                const int e = e0 + 64 * u;
+                if (e < ld) {
+                    float r = 0.f;
+                    if (e < d) {
+                        const double x = to_f64<SrcT>(v[u]);
+                        r = (float)(normalize ? x / inv : x);
+                    }
+                    o[e] = from_f32<DstT>(r);
+                }
+            }
         }
     }
 }
