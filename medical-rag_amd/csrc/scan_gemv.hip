@@ -125,10 +125,24 @@ __global__ __launch_bounds__(waves_per_group(QB) * 64) void scan_topk_kernel(Sca
             const float* src = a.q_raw + (size_t)b * a.d;
             double ss = 0.0;
             bool bad = false;
-            for (int e = lane; e < a.d; e += 64) {
-                const double x = (double)src[e];
-                bad |= !(fabs(x) <= 1.7976931348623157e308);
-                ss += x * x;
+            // A lane's loads go out sixteen at a time (one at a time they cost a
+            // memory round trip each, ten microseconds before the first row is read).
+            constexpr int kBatch = 16;
+            for (int e0 = lane; e0 < a.d; e0 += 64 * kBatch) {
+                float v[kBatch];
+#pragma unroll
+                for (int u = 0; u < kBatch; ++u) {
+                    const int e = e0 + 64 * u;
+                    v[u] = src[e < a.d ? e : lane];   // lane < d whenever this loop runs
+                }
+#pragma unroll
+                for (int u = 0; u < kBatch; ++u) {
+                    if (e0 + 64 * u < a.d) {
+                        const double x = (double)v[u];
+                        bad |= !(fabs(x) <= 1.7976931348623157e308);
+                        ss += x * x;
+                    }
+                }
             }
             if (__ballot(bad) != 0ull && lane == 0 && blockIdx.x == 0) atomicOr(a.nonfinite_flag, 1);
 #pragma unroll
@@ -143,7 +157,19 @@ __global__ __launch_bounds__(waves_per_group(QB) * 64) void scan_topk_kernel(Sca
                 norm = sqrt(ss);
                 if (!(norm >= 10.0 * 2.220446049250313e-16)) norm = 1.0;
             }
-            for (int e = lane; e < a.qstride; e += 64) dst[e] = e < a.d ? (float)((double)src[e] / norm) : 0.f;
+            for (int e0 = lane; e0 < a.qstride; e0 += 64 * kBatch) {
+                float v[kBatch];
+#pragma unroll
+                for (int u = 0; u < kBatch; ++u) {
+                    const int e = e0 + 64 * u;
+                    v[u] = src[e < a.d ? e : 0];
+                }
+#pragma unroll
+                for (int u = 0; u < kBatch; ++u) {
+                    const int e = e0 + 64 * u;
+                    if (e < a.qstride) dst[e] = e < a.d ? (float)((double)v[u] / norm) : 0.f;
+                }
+            }
         }
     } else {
         const int n4 = QB * a.qstride / 4;
