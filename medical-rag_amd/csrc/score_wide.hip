@@ -99,33 +99,56 @@ struct WideArgs {
     int debug;                // timing experiments only: bit 0 nothing reaches the floor
 };
 
+// Addresses of the tile loads are a wave-uniform base (scalar registers) plus a
+// 32-bit lane offset: lane L of a 1 KiB piece fetches 16-byte chunk (L % 8) ^ (L / 8)
+// of row L / 8 of the piece's eight rows.  Kept in that form, a request costs no
+// 64-bit vector address per piece, which matters once its pieces are spread
+// between the MFMAs and their addresses live that long.
+// A pointer the compiler must treat as one opaque scalar value (it otherwise
+// folds the lane offset into the 64-bit sum and carries a vector address).
+__device__ __forceinline__ const char* scalar_pointer(const char* p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)v);
+    const unsigned int hi = __builtin_amdgcn_readfirstlane((unsigned int)(v >> 32));
+    return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+}
+
+__device__ __forceinline__ unsigned int lane_piece_offset(int lane, unsigned int row_bytes) {
+    return (unsigned int)(lane >> 3) * row_bytes + (unsigned int)(((lane & 7) ^ (lane >> 3)) << 4);
+}
+
 // This wave's share (4 of 32 instructions) of the two query halves of a K step.
+// wave: wave-uniform (scalar) wave number.
 __device__ __forceinline__ void request_queries(const char* qbase, long long row_bytes, int k0_bytes, char* dst, int wave,
-                                                int lane) {
+                                                unsigned int lane_off) {
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int t = wave * 2 + i;
-            const int r = h * 128 + t * 8 + (lane >> 3);
-            const int chunk = (lane & 7) ^ (lane >> 3);
-            const char* src = qbase + r * row_bytes + k0_bytes + chunk * 16;
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(dst + (2 + h) * kHalfBytes + t * 1024), 16, 0, 0);
+            const char* base = scalar_pointer(qbase + (long long)(h * 128 + t * 8) * row_bytes + k0_bytes);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + lane_off), (lds_ptr_t)(dst + (2 + h) * kHalfBytes + t * 1024), 16, 0, 0);
         }
 }
 
 // ... and of ITS GROUP's row half (16 instructions over the group's 4 waves).
 // Rows past the end of the matrix are fetched as copies of the last row.
 __device__ __forceinline__ void request_rows(const char* rows, long long row0, long long row_max, long long row_bytes,
-                                             int k0_bytes, char* dst, int wave_in_group, int lane) {
+                                             int k0_bytes, char* dst, int wave_in_group, int lane, unsigned int lane_off) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int t = wave_in_group * 4 + i;
-        long long row = row0 + t * 8 + (lane >> 3);
-        row = row < row_max ? row : row_max;
-        const int chunk = (lane & 7) ^ (lane >> 3);
-        const char* src = rows + row * row_bytes + k0_bytes + chunk * 16;
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(dst + t * 1024), 16, 0, 0);
+        const long long g0 = row0 + t * 8;                                   // the piece's first row (uniform)
+        const long long gbase = g0 < row_max ? g0 : row_max;
+        const char* base = scalar_pointer(rows + gbase * row_bytes + k0_bytes);
+        // Rows of the piece beyond its first that exist: 7 everywhere but in the last
+        // tile, where every lane's row is clamped to the last one (no branch: a
+        // branch here would cut the requests off from the MFMAs they are spread between).
+        const long long left = row_max - g0;
+        const int valid = left < 0 ? 0 : left > 7 ? 7 : (int)left;
+        const int r = (lane >> 3) < valid ? (lane >> 3) : valid;
+        const unsigned int off = (unsigned int)r * (unsigned int)row_bytes + (unsigned int)(((lane & 7) ^ (lane >> 3)) << 4);
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + off), (lds_ptr_t)(dst + t * 1024), 16, 0, 0);
     }
 }
 
@@ -140,18 +163,52 @@ __device__ __forceinline__ void barrier_keeping_loads() {
     asm volatile("" ::: "memory");
 }
 
-// The 64-row x 64-query half of a wave's tile, one K step: 4 x 4 tiles of 16 x 16,
-// two K blocks of 32.  FIRST: the sums start from zero instead of acc.
+// One K step of a wave's low rows (row tiles 0-3): the eight MFMAs of a row
+// tile (4 query tiles x two K blocks of 32), then the two LDS reads that replace
+// its fragments with those of the high rows, which land while the next row tiles
+// multiply.  The order is pinned with sched_group_barrier; left to itself the
+// compiler issues all reads after all MFMAs and the wave then waits for them.
+// FIRST: the sums start from zero instead of acc.
 template <bool FIRST>
-__device__ __forceinline__ void mfma_half(const bf16x8 (&fa)[4][2], const bf16x8 (&fb)[4][2], f32x4 (&acc)[8][4], int m0) {
+__device__ __forceinline__ void mfma_low_rows(bf16x8 (&fa)[4][2], const bf16x8 (&fb)[4][2], f32x4 (&acc)[8][4],
+                                              const char* sa, int lane) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+#pragma unroll
+        for (int nn = 0; nn < 4; ++nn) {
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            f32x4 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m][0], fb[nn][0], FIRST ? zero : acc[m][nn], 0, 0, 0);
+            acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m][1], fb[nn][1], c, 0, 0, 0);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) fa[m][kk] = read_frag(sa, 64 + m * 16 + (lane & 15), 4 * kk + (lane >> 4));
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);  // eight MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // two LDS reads
+    }
+}
+
+// ... and of its high rows (row tiles 4-7).  The caller has just requested the
+// eight 1 KiB pieces of a later K step; they are issued one per four MFMAs
+// instead of as a burst in front of them (a piece costs its wave 100-200 cycles
+// of issue, which the matrix cores otherwise spend idle).
+template <bool FIRST>
+__device__ __forceinline__ void mfma_high_rows(const bf16x8 (&fa)[4][2], const bf16x8 (&fb)[4][2], f32x4 (&acc)[8][4]) {
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int nn = 0; nn < 4; ++nn) {
             const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-            f32x4 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m][0], fb[nn][0], FIRST ? zero : acc[m0 + m][nn], 0, 0, 0);
-            acc[m0 + m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m][1], fb[nn][1], c, 0, 0, 0);
+            f32x4 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m][0], fb[nn][0], FIRST ? zero : acc[4 + m][nn], 0, 0, 0);
+            acc[4 + m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m][1], fb[nn][1], c, 0, 0, 0);
         }
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // one load
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // four MFMAs
+    }
 }
 
 // MAX_ONLY: the sampling form (a.tile_max), which keeps nothing but each
@@ -160,7 +217,7 @@ template <bool MAX_ONLY>
 __global__ __launch_bounds__(kWideThreads, 2) void score_filter_wide_kernel(WideArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the load addresses build on it
     const int wm = wave >> 2, wn = wave & 3;
     // XCD-aware, bijective workgroup remap: ids that land on one XCD become consecutive.
     const int nwg = gridDim.x, xcd = blockIdx.x % 8, per = nwg / 8, rem = nwg % 8;
@@ -195,19 +252,23 @@ __global__ __launch_bounds__(kWideThreads, 2) void score_filter_wide_kernel(Wide
     // loop's counted waits assume that nothing else is in flight.
     asm volatile("" ::"v"(thr[0]), "v"(thr[1]), "v"(thr[2]), "v"(thr[3]) : "memory");
 
+    const unsigned int lane_off = lane_piece_offset(lane, (unsigned int)row_bytes);
     // load cursor: the next K step to request
     long long ld_tile = tile_first;
     int ld_ks = 0, ld_buf = 0;
     auto request_step = [&]() {
         char* dst = smem + ld_buf * kWideStepBytes;
-        request_queries(qbase, row_bytes, ld_ks * 128, dst, wave, lane);
+        request_queries(qbase, row_bytes, ld_ks * 128, dst, wave, lane_off);
         request_rows(a.rows, ld_tile * a.tile_stride * kWideTile + wm * 128, a.n - 1, row_bytes, ld_ks * 128,
-                     dst + wm * kHalfBytes, wn, lane);
+                     dst + wm * kHalfBytes, wn, lane, lane_off);
         ld_buf ^= 1;
         if (++ld_ks == ksteps) { ld_ks = 0; ld_tile += tile_step; }
     };
-    if (total > 0) request_step();
-    if (total > 1) request_step();
+    // Two K steps are always in flight, also past a workgroup's last step (the
+    // cursor then runs on: rows are clamped to the matrix, and what lands goes to
+    // a buffer nobody reads again), so that the loop requests without a branch.
+    request_step();
+    request_step();
 
     // acc[m][nn]: rows 16 m + 4 (lane / 16) + r of the wave's 128, query 16 nn + lane % 16 of its 64
     f32x4 acc[8][4];
@@ -219,8 +280,7 @@ __global__ __launch_bounds__(kWideThreads, 2) void score_filter_wide_kernel(Wide
             for (int r = 0; r < 4; ++r) acc[m][nn][r] = 0.f;   // (every tile's first K step overwrites them)
 
     // step 0 has landed for everybody; then group 1 falls one barrier behind
-    if (total > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     barrier_keeping_loads();
     if (wm == 1) barrier_keeping_loads();
 
@@ -239,10 +299,7 @@ __global__ __launch_bounds__(kWideThreads, 2) void score_filter_wide_kernel(Wide
         const char* sb = buf + (2 + (wn >> 1)) * kHalfBytes;
         const int qrow = (wn & 1) * 64;
         // this group's rows of step s (its queries were waited for before the previous barrier)
-        if (s > 0) {
-            if (s + 1 < total) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        if (s > 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         barrier_keeping_loads();                                   // first barrier of the step
         // Fragment of a 16 x 32 block: lane l holds elements 8 (l / 16) .. +7 of row l % 16.
         bf16x8 fb[4][2], fa[4][2];
@@ -258,25 +315,26 @@ __global__ __launch_bounds__(kWideThreads, 2) void score_filter_wide_kernel(Wide
         // A tile's first K step starts its sums from the constant zero, which
         // spares the epilogue 128 register clears per tile.
         const bool first = ks == 0;
-        __builtin_amdgcn_s_setprio(1);
-        if (first) mfma_half<true>(fa, fb, acc, 0);
-        else mfma_half<false>(fa, fb, acc, 0);
-        __builtin_amdgcn_s_setprio(0);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int m = 0; m < 4; ++m) fa[m][kk] = read_frag(sa, 64 + m * 16 + (lane & 15), 4 * kk + (lane >> 4));
-        // the queries of step s + 1: the older four of the eight loads in flight
-        if (s + 1 < total) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        barrier_keeping_loads();                                   // third barrier
-        // On a tile's last K step the request waits until the tile's appends are
-        // issued: a store behind eight 1 KiB loads stalls the wave until the
-        // memory pipeline has taken them.
         const bool tile_done = ks + 1 == ksteps;
-        if (!tile_done && s + 2 < total) request_step();
         __builtin_amdgcn_s_setprio(1);
-        if (first) mfma_half<true>(fa, fb, acc, 4);
-        else mfma_half<false>(fa, fb, acc, 4);
+        if (first) mfma_low_rows<true>(fa, fb, acc, sa, lane);
+        else mfma_low_rows<false>(fa, fb, acc, sa, lane);
+        __builtin_amdgcn_s_setprio(0);
+        // the queries of step s + 1: the older four of the eight loads in flight
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        barrier_keeping_loads();                                   // third barrier
+        // The buffers of step s are free: step s + 2 is requested, its pieces spread
+        // between the MFMAs.  (One branch per form of the MFMAs and nothing else: with
+        // a third, request-free copy for a tile's last step the compiler spilled 200
+        // registers.)
+        __builtin_amdgcn_s_setprio(1);   // the priority change bounds what the scheduler may interleave: requests go inside it
+        if (first) {
+            request_step();
+            mfma_high_rows<true>(fa, fb, acc);
+        } else {
+            request_step();
+            mfma_high_rows<false>(fa, fb, acc);
+        }
         __builtin_amdgcn_s_setprio(0);
 
         if (tile_done) {
@@ -329,7 +387,6 @@ __global__ __launch_bounds__(kWideThreads, 2) void score_filter_wide_kernel(Wide
                     }
                 }
             }
-            if (s + 2 < total) request_step();
             ks = 0;
             tile += tile_step;
         } else {
@@ -337,6 +394,8 @@ __global__ __launch_bounds__(kWideThreads, 2) void score_filter_wide_kernel(Wide
         }
     }
     if (wm == 0) barrier_keeping_loads();   // group 0 catches up with group 1's last barrier
+    // the two requests past the last step must have landed before the LDS is given back
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if constexpr (!MAX_ONLY) {
 #pragma unroll
         for (int nn = 0; nn < 4; ++nn) {

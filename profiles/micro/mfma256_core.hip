@@ -503,6 +503,162 @@ __global__ __launch_bounds__(kThreads, 2) void pingpong16_kernel(const char* row
     }
 }
 
+// The 16x16x32 form with the K-step requests issued unconditionally and spread
+// between the MFMAs of the step's second half by sched_group_barrier.
+__global__ __launch_bounds__(kThreads, 2) void pingpong16i_kernel(const char* rows, long long n, int ld, const char* queries,
+                                                               int n_ranges, long long tiles_per_range,
+                                                               unsigned int* tile_max, int mode) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned int* best = reinterpret_cast<unsigned int*>(smem + 2 * kStepBytes);  // [256]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int nwg = gridDim.x, xcd = blockIdx.x % 8, per = nwg / 8, rem = nwg % 8;
+    const int wgid = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + blockIdx.x / 8;
+    const int qt = wgid / n_ranges, range = wgid % n_ranges;
+    const long long n_tiles = (n + 255) / 256;
+    const long long tile_lo = (long long)range * tiles_per_range;
+    long long tile_hi = tile_lo + tiles_per_range;
+    if (tile_hi > n_tiles) tile_hi = n_tiles;
+    const int ksteps = ld / 64;
+    const long long row_bytes = (long long)ld * 2;
+    const char* qbase = queries + (size_t)qt * 256 * row_bytes;
+    const long long total = (tile_hi > tile_lo ? tile_hi - tile_lo : 0) * ksteps;
+    if (tid < 256) best[tid] = 0u;
+
+    long long ld_tile = tile_lo;
+    int ld_ks = 0, ld_buf = 0;
+    // four loads per wave: this wave's share of both query halves ...
+    auto request_queries = [&]() {
+        char* dst = smem + ld_buf * kStepBytes;
+        stage_half(qbase, 0, 255, row_bytes, ld_ks * 128, dst + 2 * kHalfBytes, wave, lane);
+        stage_half(qbase, 128, 255, row_bytes, ld_ks * 128, dst + 3 * kHalfBytes, wave, lane);
+    };
+    // ... and four more: its share of ITS GROUP's row half (16 instructions over 4 waves)
+    auto request_rows = [&]() {
+        char* dst = smem + ld_buf * kStepBytes + wm * kHalfBytes;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int t = (wave & 3) * 4 + i;
+            const int r = t * 8 + (lane >> 3);
+            long long row = ld_tile * 256 + wm * 128 + r;
+            row = row < n - 1 ? row : n - 1;
+            const int chunk = (lane & 7) ^ (lane >> 3);
+            const char* src = rows + row * row_bytes + ld_ks * 128 + chunk * 16;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(dst + t * 1024), 16, 0, 0);
+        }
+        ld_buf ^= 1;
+        if (++ld_ks == ksteps) { ld_ks = 0; ++ld_tile; }
+    };
+    if (total > 0) { request_queries(); request_rows(); }
+    if (total > 1) { request_queries(); request_rows(); }
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int nn = 0; nn < 4; ++nn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[m][nn][r] = 0.f;
+
+    // step 0 has landed for everybody; then group 1 falls one barrier behind
+    if (total > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    barrier_keeping_loads();
+    if (wm == 1) barrier_keeping_loads();
+
+    long long tile = tile_lo;
+    int ks = 0;
+    long long flush_tile = -1;  // a finished tile whose maxima group 1 still has to write out
+    for (long long s = 0; s < total; ++s) {
+        const char* buf = smem + (int)(s & 1) * kStepBytes;
+        const char* sa = buf + wm * kHalfBytes;
+        const char* sb = buf + (2 + (wn >> 1)) * kHalfBytes;
+        const int qrow = (wn & 1) * 64;
+        // this group's rows of step s (its queries were waited for before the previous barrier)
+        if (s > 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        barrier_keeping_loads();                                   // first barrier of the step
+        if (flush_tile >= 0 && wm == 1) {                            // both groups' maxima of that tile are in
+            tile_max[((size_t)qt * 256 + (tid - 256)) * n_tiles + flush_tile] = best[tid - 256];
+            best[tid - 256] = 0u;
+        }
+        flush_tile = -1;
+        bf16x8 fb[4][2], fa[4][2];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int nn = 0; nn < 4; ++nn) fb[nn][kk] = read_frag(sb, qrow + nn * 16 + (lane & 15), 4 * kk + (lane >> 4));
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) fa[m][kk] = read_frag(sa, m * 16 + (lane & 15), 4 * kk + (lane >> 4));
+        barrier_keeping_loads();                                   // second barrier
+        // Low rows: the eight MFMAs of row tile m, then the two reads that replace its
+        // fragments with those of the high rows (they land while the next tiles multiply).
+        if (mode & 4) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+#pragma unroll
+            for (int nn = 0; nn < 4; ++nn)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+                    acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m][kk], fb[nn][kk], acc[m][nn], 0, 0, 0);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) fa[m][kk] = read_frag(sa, 64 + m * 16 + (lane & 15), 4 * kk + (lane >> 4));
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);  // eight MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // two LDS reads
+        }
+        if (mode & 4) __builtin_amdgcn_s_setprio(0);
+        // queries of step s + 1: only this step's... no later loads exist yet beyond rows(s+1)
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        barrier_keeping_loads();                                   // third barrier
+        // Requests without a branch (past the last step they re-read clamped rows into a
+        // buffer nobody reads again), spread between the MFMAs: one 1 KiB piece per four.
+        request_queries();
+        request_rows();
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int nn = 0; nn < 4; ++nn)
+                    acc[4 + m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m][kk], fb[nn][kk], acc[4 + m][nn], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // one VMEM read
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // four MFMAs
+        }
+        if (ks + 1 == ksteps) {
+#pragma unroll
+            for (int nn = 0; nn < 4; ++nn) {
+                float mx = -__builtin_huge_valf();
+#pragma unroll
+                for (int m = 0; m < 8; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        mx = fmaxf(mx, acc[m][nn][r]);
+                        acc[m][nn][r] = 0.f;
+                    }
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                if (lane < 16) atomicMax(&best[wn * 64 + nn * 16 + lane], order_f32(mx));
+            }
+            flush_tile = tile;
+            ks = 0;
+            ++tile;
+        } else {
+            ++ks;
+        }
+    }
+    if (wm == 0) barrier_keeping_loads();   // group 0 catches up with group 1's last barrier
+    barrier_keeping_loads();                // every wave's maxima are in LDS
+    if (flush_tile >= 0 && wm == 1) {
+        tile_max[((size_t)qt * 256 + (tid - 256)) * n_tiles + flush_tile] = best[tid - 256];
+    }
+}
+
 // plain check kernel: best score of query q over row tile t
 __global__ void check_kernel(const bf16_t* rows, long long n, int ld, const bf16_t* queries, int n_q, long long n_tiles,
                              unsigned int* out) {
@@ -554,9 +710,11 @@ int main(int argc, char** argv) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(core_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pingpong_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const bool pingpong = argc > 4 && atoi(argv[4]) >= 1;
-    const bool m16 = argc > 4 && atoi(argv[4]) == 2;
+    const bool m16 = argc > 4 && atoi(argv[4]) >= 2;
+    const bool m16i = argc > 4 && atoi(argv[4]) == 3;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pingpong16i_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pingpong16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    auto kernel = m16 ? pingpong16_kernel : pingpong ? pingpong_kernel : core_kernel;
+    auto kernel = m16i ? pingpong16i_kernel : m16 ? pingpong16_kernel : pingpong ? pingpong_kernel : core_kernel;
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
@@ -574,7 +732,7 @@ int main(int argc, char** argv) {
             (void)hipEventElapsedTime(&ms, e0, e1);
             if (r >= 1) sum += ms;
         }
-        printf("{\"kernel\": \"%s\", \"mode\": \"%s\", \"ms\": %.4f, \"TFLOPs\": %.1f}\n", m16 ? "pingpong_16x16x32" : pingpong ? "pingpong" : "lockstep", mode == 0 ? "full" : mode == 1 ? "loads_only" : mode == 2 ? "mfma_only" : "full_setprio",
+        printf("{\"kernel\": \"%s\", \"mode\": \"%s\", \"ms\": %.4f, \"TFLOPs\": %.1f}\n", m16i ? "pingpong_16x16x32_interleaved" : m16 ? "pingpong_16x16x32" : pingpong ? "pingpong" : "lockstep", mode == 0 ? "full" : mode == 1 ? "loads_only" : mode == 2 ? "mfma_only" : "full_setprio",
                sum / reps, flops / (sum / reps) / 1e9);
         if (hipGetLastError() != hipSuccess) { printf("launch error\n"); return 1; }
     }
