@@ -696,8 +696,19 @@ int main(int argc, char** argv) {
     std::vector<bf16_t> h_rows((size_t)n * ld), h_q((size_t)n_q * ld);
     unsigned int seed = 12345;
     auto rnd = [&]() { seed = seed * 1664525u + 1013904223u; return (bf16_t)(((seed >> 9) & 0x7f) | 0x3c00 | ((seed >> 1) & 0x8000)); };  // +-[0.0078, 0.0156)
-    for (auto& v : h_rows) v = rnd();
-    for (auto& v : h_q) v = rnd();
+    // argv[5] = 1: roughly normal values of scale 1/32 (what normalised rows of 1024 look like)
+    // instead of one binade of uniform ones: the clock the chip holds depends on the data.
+    const bool gaussian = argc > 5 && atoi(argv[5]) == 1;
+    auto gauss = [&]() {
+        float acc = 0.f;
+        for (int i = 0; i < 4; ++i) { seed = seed * 1664525u + 1013904223u; acc += (float)(seed >> 8) / 16777216.f - 0.5f; }
+        const float x = acc * 1.7320508f / 32.f;
+        unsigned int u;
+        memcpy(&u, &x, 4);
+        return (bf16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+    };
+    for (auto& v : h_rows) v = gaussian ? gauss() : rnd();
+    for (auto& v : h_q) v = gaussian ? gauss() : rnd();
     bf16_t *d_rows, *d_q;
     unsigned int *d_out, *d_ref;
     if (hipMalloc(reinterpret_cast<void**>(&d_rows), h_rows.size() * 2) != hipSuccess) return 1;
