@@ -207,12 +207,15 @@ int enqueue_mfma(mtr_index* ix, const mtr::MfmaPlan& plan, const void* dev_queri
     }
     // Otherwise the general kernel samples for itself (the fallback behind the
     // wide kernel starts without floors).
-    const int stride = (big && !use_wide) ? sample_stride(ix->n, plan.n_tiles, k) : 0;
+    // The sampling launch works on 128-row tiles whatever the full launch uses.
+    const long long stiles = (ix->n + 127) / 128;
+    const int stride = (big && !use_wide) ? sample_stride(ix->n, stiles, k) : 0;
     mtr::MfmaPlan samp = plan;
     if (stride >= 2) {
-        const long long n_samp = (plan.n_tiles + stride - 1) / stride;
-        if (mtr::plan_mfma(ix->dtype, n_samp * plan.tm, ix->ld, b, k, ix->num_cus, &samp) != 0)
+        const long long n_samp = (stiles + stride - 1) / stride;
+        if (mtr::plan_mfma(ix->dtype, n_samp * 128, ix->ld, b, k, ix->num_cus, 1, &samp) != 0 || samp.tm != 128)
             return fail(MTR_ERR_INVALID, "internal: no launch shape for the sampling launch");
+        // (its query tiles may be narrower than the full launch's: both index queries and floors by query number)
     }
     const size_t q_row_bytes = (size_t)ix->ld * dtype_size(ix->dtype);
     const int64_t q_rows = std::max<int64_t>((int64_t)plan.n_qtiles * plan.tnq, use_wide ? (int64_t)wide.n_qtiles * 256 : 0);
@@ -304,7 +307,7 @@ int enqueue_search(mtr_index* ix, const void* dev_queries, int q_dtype, int b, i
         return fail(MTR_ERR_INVALID, "cosine search needs a shard built with normalize=1");
     if (b >= mfma_min_batch(ix->dtype)) {
         mtr::MfmaPlan mplan;
-        if (mtr::plan_mfma(ix->dtype, ix->n, ix->ld, b, k, ix->num_cus, &mplan) == 0)
+        if (mtr::plan_mfma(ix->dtype, ix->n, ix->ld, b, k, ix->num_cus, 0, &mplan) == 0)
             return enqueue_mfma(ix, mplan, dev_queries, q_dtype, b, k, metric, dev_out_idx, dev_out_score, stream);
     }
     mtr::ScanPlan plan;

@@ -94,7 +94,7 @@ struct MfmaPlan {
     int cap;                  // candidate slots per (workgroup, query): 256 or 512
     int slack;                // extra keys an in-loop re-selection may keep
     int tnq;                  // queries per tile: 32, 64 or 128 by batch size
-    int tm;                   // rows per tile
+    int tm;                   // rows per tile: 128, or 256 (64-query tiles in the ring form, eight waves)
     long long n_tiles;        // row tiles covered by the launch
     int n_qtiles;             // query tiles
     int n_ranges;             // row ranges (= candidate lists per query)
@@ -108,7 +108,8 @@ struct MfmaPlan {
 
 // Launch shape of the matrix-core scoring kernel; -1 when the shape is not
 // covered (row stride not a multiple of 128 bytes or shorter than 256, or k > 256).
-int plan_mfma(int dtype, int64_t n, int ld, int b, int k, int num_cus, MfmaPlan* plan);
+// sampling: the shape of a sampling launch (128-row tiles, two buffers, default cache policy).
+int plan_mfma(int dtype, int64_t n, int ld, int b, int k, int num_cus, int sampling, MfmaPlan* plan);
 
 // Which row tiles of the matrix one launch covers and what it keeps.  Large
 // shards are searched in two launches: a sampling launch over every

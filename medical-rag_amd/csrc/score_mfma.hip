@@ -52,11 +52,11 @@ namespace {
 // that small batches do not pay for 128 columns.  Four waves per workgroup:
 // TNQ 128: waves 2x2, each 64 rows x 64 queries = 2x2 MFMA tiles; 64: waves 2x2,
 // each 64 x 32 = 2x1; 32: waves 4x1, each 32 x 32.
-constexpr int TM = 128;
+constexpr int kTileRows = 128;   // rows per tile (256 in the tall form of the 64-query tile)
 constexpr int kThreads = 256;
 constexpr int kStepBytes = 128;  // K bytes of a row per step: 64 bf16 or 32 fp32
-constexpr int stage_bytes(int tnq) { return (TM + tnq) * kStepBytes; }  // row tile then query tile
-constexpr int lds_bytes(int tnq, int stages) { return stages * stage_bytes(tnq) + tnq * 12 + (kThreads / 64) * 1024; }
+constexpr int stage_bytes(int tm, int tnq) { return (tm + tnq) * kStepBytes; }  // row tile then query tile
+constexpr int lds_bytes(int tm, int tnq, int stages) { return stages * stage_bytes(tm, tnq) + tnq * 12 + (tm == 256 ? 8 : 4) * 1024; }
 
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -354,19 +354,24 @@ __device__ __forceinline__ void write_range_lists(int q0, int nq, int qt_base, i
 // that everybody is done with step s - 1, waits are counted (loads return in
 // order, so "at most N outstanding" means all but the newest N have landed) and
 // the barriers leave loads in flight, so the memory pipeline never runs empty.
-template <typename T, int CAP, int TNQ, bool MAX_ONLY, int ROW_AUX, int NS>
-__global__ __launch_bounds__(kThreads, 2) void score_topk_mfma_kernel(MfmaArgs a) {
+// TM: rows per tile.  256 (64-query tiles in the ring form only): eight waves,
+// each 32 rows x 64 queries, one workgroup per CU; the query tile's re-staging
+// then adds a quarter to the row bytes that go into LDS instead of a half.
+template <typename T, int CAP, int TNQ, bool MAX_ONLY, int ROW_AUX, int NS, int TM = kTileRows>
+__global__ __launch_bounds__(TM == 256 ? 512 : 256, TM == 256 ? 1 : 2) void score_topk_mfma_kernel(MfmaArgs a) {
     static_assert(NS == 2 || (NS == 3 && !MAX_ONLY), "the ring form exists for the full launch only");
+    static_assert(TM == 128 || (TM == 256 && TNQ == 64 && NS == 3), "the tall tile exists for 64 queries in the ring form");
+    constexpr int kThreads = TM == 256 ? 512 : 256;
     if (a.run_if && *a.run_if == 0) return;
     constexpr int TN = TNQ;
     constexpr int WAVES = kThreads / 64;
-    constexpr int WN = TNQ == 32 ? 1 : 2;                   // waves along the queries
+    constexpr int WN = (TNQ == 32 || TM == 256) ? 1 : 2;    // waves along the queries
     constexpr int WM = WAVES / WN;                          // ... and along the rows
     constexpr int MT = TM / (32 * WM);           // MFMA tiles per wave along the rows
     constexpr int NT = TNQ / (32 * WN);          // ... and along the queries
     constexpr int QPW = TNQ / WAVES;             // queries each wave looks after
     static_assert(CAP >= 2 * TM, "a tile may append TM keys per query on top of k + slack kept ones");
-    constexpr int kStageBytes = stage_bytes(TNQ);
+    constexpr int kStageBytes = stage_bytes(TM, TNQ);
     constexpr int BK = kStepBytes / (int)sizeof(T);
     static_assert((CAP & (CAP - 1)) == 0, "CAP must be a power of two");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -575,54 +580,60 @@ __global__ __launch_bounds__(kThreads, 2) void score_topk_mfma_kernel(MfmaArgs a
 }  // namespace
 
 
-int plan_mfma(int dtype, int64_t n, int ld, int b, int k, int num_cus, MfmaPlan* plan) {
+int plan_mfma(int dtype, int64_t n, int ld, int b, int k, int num_cus, int sampling, MfmaPlan* plan) {
     const int esize = dtype == 0 ? 4 : 2;
     if ((ld * esize) % kStepBytes != 0 || ld * esize < 2 * kStepBytes || k < 1 || k > 256 || b < 1 || n < 1) return -1;
-    plan->cap = k <= 32 ? 256 : 512;
-    if (const char* e = getenv("MTR_MFMA_CAP")) {
-        const int c = atoi(e);
-        if ((c == 256 || c == 512) && k + 128 <= c) plan->cap = c;
-    }
     plan->tnq = b <= 32 ? 32 : b <= 64 ? 64 : 128;
     // A shard of few row tiles cannot fill the CUs with one workgroup per (row
     // tile, query tile) pair: narrower query tiles give more, shorter workgroups
     // (4032 x 4096 fp32, 34 queries: 32 workgroups of 64 queries 0.222 ms, 64 of 32
     // queries 0.139 ms; the rows are read once more, out of L2).
     {
-        const long long row_tiles = (n + TM - 1) / TM;
+        const long long row_tiles = (n + kTileRows - 1) / kTileRows;
         while (plan->tnq > 32 && row_tiles * ((b + plan->tnq - 1) / plan->tnq) < num_cus) plan->tnq /= 2;
     }
     if (const char* e = getenv("MTR_MFMA_TNQ")) {
         const int t = atoi(e);
         if (t == 32 || t == 64 || t == 128) plan->tnq = t;
     }
-    const int tm = TM;
-    plan->slack = (plan->cap - tm - k) / 4;
-    if (plan->slack > 64) plan->slack = 64;
     plan->n_qtiles = (b + plan->tnq - 1) / plan->tnq;
-    plan->tm = tm;
-    const long long n_tiles = (n + tm - 1) / tm;
-    plan->n_tiles = n_tiles;
     // Row loads carry the streaming (nt) policy when every row byte is fetched
     // once per launch -- a single query tile -- and the rows exceed the Infinity
     // Cache: 16-byte direct-to-LDS loads then read 7.05 TB/s against 6.2 TB/s
     // under the default policy (profiles/micro/tile_read_patterns.hip).  With
     // several query tiles the later ones find the rows in L2, which streaming
-    // lines would leave first.
-    plan->stream_rows = (plan->n_qtiles == 1 && (double)n * ld * esize > 192.0 * 1024 * 1024) ? 1 : 0;
-    if (const char* e = getenv("MTR_MFMA_STREAM_ROWS")) plan->stream_rows = atoi(e) != 0;
+    // lines would leave first.  (A sampling launch reads a small part of the
+    // rows, which the full launch reads again: default policy, two buffers.)
+    plan->stream_rows = (!sampling && plan->n_qtiles == 1 && (double)n * ld * esize > 192.0 * 1024 * 1024) ? 1 : 0;
+    if (const char* e = getenv("MTR_MFMA_STREAM_ROWS")) plan->stream_rows = !sampling && atoi(e) != 0;
     // ... and, for the 32- and 64-query tiles of bf16 shards, the three-buffer
     // ring (12.5M x 768 bf16, 64 queries: 3.16 -> 3.07 ms; 1M x 1024: 0.394 ->
     // 0.375 ms; fp32 shards are bound by the fp32 matrix rate there and lose 1-2 %
     // to the ring's two workgroups per CU).
     plan->stages = (plan->stream_rows && plan->tnq <= 64 && dtype == 2) ? 3 : 2;
-    if (const char* e = getenv("MTR_MFMA_STAGES")) plan->stages = (atoi(e) == 3 && plan->tnq <= 64) ? 3 : 2;
+    if (const char* e = getenv("MTR_MFMA_STAGES")) plan->stages = (!sampling && atoi(e) == 3 && plan->tnq <= 64) ? 3 : 2;
+    // ... with 256-row tiles (eight waves) for the 64-query tile (bf16, k <= 128).
+    int tm = kTileRows;
+    const bool tall_ok = plan->stages == 3 && plan->tnq == 64 && dtype == 2 && k <= 128;
+    if (tall_ok) tm = 256;
+    if (const char* e = getenv("MTR_MFMA_TILE_ROWS")) tm = (atoi(e) == 256 && tall_ok) ? 256 : kTileRows;
+    plan->cap = (k <= 32 && tm == 128) ? 256 : 512;
+    if (const char* e = getenv("MTR_MFMA_CAP")) {
+        const int c = atoi(e);
+        if ((c == 256 || c == 512) && k + tm <= c) plan->cap = c;
+    }
+    plan->slack = (plan->cap - tm - k) / 4;
+    if (plan->slack > 64) plan->slack = 64;
+    plan->tm = tm;
+    const long long n_tiles = (n + tm - 1) / tm;
+    plan->n_tiles = n_tiles;
     // Workgroups per CU (= row ranges x query tiles / CUs): more, shorter row
     // ranges cost more in top-k selection than they gain in bytes in flight.
     // Measured best with two buffers: 3 for the 32-query tile (four fit), 2 for
-    // the 64- and 128-query tiles.  Two ring workgroups fit a CU's LDS.
-    long long per_cu = plan->stages == 3 ? 2 : plan->tnq == 32 ? 3 : 2;
-    if (const char* e = getenv("MTR_MFMA_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
+    // the 64- and 128-query tiles.  Two ring workgroups fit a CU's LDS, one of
+    // the eight-wave 256-row form.
+    long long per_cu = tm == 256 ? 1 : plan->stages == 3 ? 2 : plan->tnq == 32 ? 3 : 2;
+    if (const char* e = getenv("MTR_MFMA_PER_CU")) per_cu = (atoi(e) > 0 && tm != 256) ? atoi(e) : per_cu;
     // rounded down: a grid a few workgroups above per_cu * CUs runs those in a second round
     long long ranges = per_cu * num_cus / plan->n_qtiles;
     if (ranges > n_tiles) ranges = n_tiles;
@@ -630,7 +641,7 @@ int plan_mfma(int dtype, int64_t n, int ld, int b, int k, int num_cus, MfmaPlan*
     plan->tiles_per_range = (n_tiles + ranges - 1) / ranges;
     plan->n_ranges = (int)((n_tiles + plan->tiles_per_range - 1) / plan->tiles_per_range);
     plan->grid = plan->n_qtiles * plan->n_ranges;
-    plan->lds = lds_bytes(plan->tnq, plan->stages);
+    plan->lds = lds_bytes(tm, plan->tnq, plan->stages);
     plan->cand_bytes = (size_t)plan->grid * plan->tnq * plan->cap * 8;
     return 0;
 }
@@ -673,7 +684,7 @@ hipError_t launch_score_mfma(const void* rows, int dtype, int64_t n, int ld, con
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kernel, dim3(plan.grid), dim3(kThreads), plan.lds, stream, a);
+        hipLaunchKernelGGL(kernel, dim3(plan.grid), dim3(plan.tm == 256 ? 512 : kThreads), plan.lds, stream, a);
         return hipGetLastError();
     };
 #define MTR_MFMA_PICK(T, AUX)                                                                         \
@@ -698,6 +709,10 @@ hipError_t launch_score_mfma(const void* rows, int dtype, int64_t n, int ld, con
         case 64: return launch(&score_topk_mfma_kernel<T, 256, 64, false, 2, 3>);                     \
         case 65: return launch(&score_topk_mfma_kernel<T, 512, 64, false, 2, 3>);                     \
         default: return hipErrorInvalidValue;                                                         \
+    }
+    if (plan.tm == 256) {
+        if (plan.stages != 3 || plan.tnq != 64 || plan.cap != 512 || dtype != 2 || a.tile_max != nullptr) return hipErrorInvalidValue;
+        return launch(&score_topk_mfma_kernel<bf16_t, 512, 64, false, 2, 3, 256>);
     }
     if (plan.stages == 3 && a.tile_max == nullptr) {
         if (dtype == 0) { MTR_MFMA_PICK_RING(float) }

@@ -496,6 +496,10 @@ def test_streaming_ring_form_equals_two_buffer_form(native, store, d, b, stride)
     ring_i, ring_s = _search_with_env(shard, queries, k, MTR_MFMA_SAMPLE_STRIDE=stride, MTR_MFMA_STREAM_ROWS=1, MTR_MFMA_STAGES=3)
     assert (base_i == nt_i).all() and (base_s == nt_s).all()
     assert (base_i == ring_i).all() and (base_s == ring_s).all()
+    # bf16 tiles of 64 queries take 256-row tiles (eight waves) in the ring form; the 128-row ring stays selectable
+    r128_i, r128_s = _search_with_env(shard, queries, k, MTR_MFMA_SAMPLE_STRIDE=stride, MTR_MFMA_STREAM_ROWS=1, MTR_MFMA_STAGES=3,
+                                      MTR_MFMA_TILE_ROWS=128)
+    assert (base_i == r128_i).all() and (base_s == r128_s).all()
     assert ring_i[0, :4].tolist() == [5, 128 * 3 + 3, 128 * 40 + 9, n - 2]
     check_topk(ring_i, ring_s, orc.scores(queries, corpus), k, 1e-6 if store == "fp32" else 2.0 ** -8)
     # the ring on a shard of a single row tile, and of fewer tiles than workgroups
