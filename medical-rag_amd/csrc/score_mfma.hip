@@ -360,12 +360,12 @@ __device__ __forceinline__ void write_range_lists(int q0, int nq, int qt_base, i
 template <typename T, int CAP, int TNQ, bool MAX_ONLY, int ROW_AUX, int NS, int TM = kTileRows>
 __global__ __launch_bounds__(TM == 256 ? 512 : 256, TM == 256 ? 1 : 2) void score_topk_mfma_kernel(MfmaArgs a) {
     static_assert(NS == 2 || (NS == 3 && !MAX_ONLY), "the ring form exists for the full launch only");
-    static_assert(TM == 128 || (TM == 256 && TNQ == 64 && NS == 3), "the tall tile exists for 64 queries in the ring form");
+    static_assert(TM == 128 || (TM == 256 && (TNQ == 64 || TNQ == 128) && NS == 3), "the tall tile exists for 64 and 128 queries in the ring form");
     constexpr int kThreads = TM == 256 ? 512 : 256;
     if (a.run_if && *a.run_if == 0) return;
     constexpr int TN = TNQ;
     constexpr int WAVES = kThreads / 64;
-    constexpr int WN = (TNQ == 32 || TM == 256) ? 1 : 2;    // waves along the queries
+    constexpr int WN = (TNQ == 32 || (TM == 256 && TNQ == 64)) ? 1 : 2;    // waves along the queries
     constexpr int WM = WAVES / WN;                          // ... and along the rows
     constexpr int MT = TM / (32 * WM);           // MFMA tiles per wave along the rows
     constexpr int NT = TNQ / (32 * WN);          // ... and along the queries
@@ -610,13 +610,16 @@ int plan_mfma(int dtype, int64_t n, int ld, int b, int k, int num_cus, int sampl
     // ring (12.5M x 768 bf16, 64 queries: 3.16 -> 3.07 ms; 1M x 1024: 0.394 ->
     // 0.375 ms; fp32 shards are bound by the fp32 matrix rate there and lose 1-2 %
     // to the ring's two workgroups per CU).
-    plan->stages = (plan->stream_rows && plan->tnq <= 64 && dtype == 2) ? 3 : 2;
-    if (const char* e = getenv("MTR_MFMA_STAGES")) plan->stages = (!sampling && atoi(e) == 3 && plan->tnq <= 64) ? 3 : 2;
-    // ... with 256-row tiles (eight waves) for the 64-query tile (bf16, k <= 128).
+    // The 128-query tile has the ring only in its 256-row form (below).
+    const bool tall_shape = plan->tnq >= 64 && dtype == 2 && k <= 128;
+    plan->stages = (plan->stream_rows && dtype == 2 && (plan->tnq <= 64 || tall_shape)) ? 3 : 2;
+    if (const char* e = getenv("MTR_MFMA_STAGES")) plan->stages = (!sampling && atoi(e) == 3 && (plan->tnq <= 64 || tall_shape)) ? 3 : 2;
+    // ... with 256-row tiles (eight waves) for the 64- and 128-query tiles (bf16, k <= 128).
     int tm = kTileRows;
-    const bool tall_ok = plan->stages == 3 && plan->tnq == 64 && dtype == 2 && k <= 128;
+    const bool tall_ok = plan->stages == 3 && tall_shape;
     if (tall_ok) tm = 256;
     if (const char* e = getenv("MTR_MFMA_TILE_ROWS")) tm = (atoi(e) == 256 && tall_ok) ? 256 : kTileRows;
+    if (tm == kTileRows && plan->tnq == 128) plan->stages = 2;
     plan->cap = (k <= 32 && tm == 128) ? 256 : 512;
     if (const char* e = getenv("MTR_MFMA_CAP")) {
         const int c = atoi(e);
@@ -711,8 +714,10 @@ hipError_t launch_score_mfma(const void* rows, int dtype, int64_t n, int ld, con
         default: return hipErrorInvalidValue;                                                         \
     }
     if (plan.tm == 256) {
-        if (plan.stages != 3 || plan.tnq != 64 || plan.cap != 512 || dtype != 2 || a.tile_max != nullptr) return hipErrorInvalidValue;
-        return launch(&score_topk_mfma_kernel<bf16_t, 512, 64, false, 2, 3, 256>);
+        if (plan.stages != 3 || plan.cap != 512 || dtype != 2 || a.tile_max != nullptr) return hipErrorInvalidValue;
+        if (plan.tnq == 64) return launch(&score_topk_mfma_kernel<bf16_t, 512, 64, false, 2, 3, 256>);
+        if (plan.tnq == 128) return launch(&score_topk_mfma_kernel<bf16_t, 512, 128, false, 2, 3, 256>);
+        return hipErrorInvalidValue;
     }
     if (plan.stages == 3 && a.tile_max == nullptr) {
         if (dtype == 0) { MTR_MFMA_PICK_RING(float) }
