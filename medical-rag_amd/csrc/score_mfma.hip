@@ -361,6 +361,7 @@ template <typename T, int CAP, int TNQ, bool MAX_ONLY, int ROW_AUX, int NS, int 
 __global__ __launch_bounds__(TM == 256 ? 512 : 256, TM == 256 ? 1 : 2) void score_topk_mfma_kernel(MfmaArgs a) {
     static_assert(NS == 2 || (NS == 3 && !MAX_ONLY), "the ring form exists for the full launch only");
     static_assert(TM == 128 || (TM == 256 && (TNQ == 64 || TNQ == 128) && NS == 3), "the tall tile exists for 64 and 128 queries in the ring form");
+    static_assert(TNQ % (8 * (TM == 256 ? 8 : 4)) == 0, "every wave stages at least one 8-row piece of the query tile");
     constexpr int kThreads = TM == 256 ? 512 : 256;
     if (a.run_if && *a.run_if == 0) return;
     constexpr int TN = TNQ;
