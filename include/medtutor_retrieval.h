@@ -18,7 +18,12 @@
  *    GPUs (one process per GPU) report global ids.
  *  - Result rows are ordered by (score descending, row id ascending); slots
  *    beyond the number of rows hold id -1 and score -inf.
- *  - Calls on one handle are serialised by an internal mutex.
+ *  - Threads and streams.  Host calls on one handle are serialised by an
+ *    internal mutex.  A handle's scratch buffers are shared by all its searches:
+ *    every call records an event behind the work it enqueued, and a call that
+ *    enqueues on a different stream first makes that stream wait for the event,
+ *    so searches on one handle run one after the other on the GPU whatever
+ *    streams they were given.
  */
 #ifndef MEDTUTOR_RETRIEVAL_H
 #define MEDTUTOR_RETRIEVAL_H
@@ -36,7 +41,7 @@ enum {
     MTR_ERR_INVALID = -1,   /* bad argument / unsupported size */
     MTR_ERR_NONFINITE = -2, /* NaN or infinity in rows or queries (sklearn raises ValueError) */
     MTR_ERR_HIP = -3,       /* HIP runtime error */
-    MTR_ERR_COMM = -4,      /* reserved: collective error */
+    MTR_ERR_COMM = -4,      /* collective (RCCL) error */
     MTR_ERR_OOM = -5        /* device allocation failed */
 };
 
@@ -84,12 +89,19 @@ int mtr_index_search(mtr_index_t* index, const void* queries, int32_t q_dtype,
 
 /* Same search with device-resident queries and outputs, enqueued on `stream`
  * (a hipStream_t; NULL = HIP's default stream) without synchronising.  The
- * caller synchronises the stream before reading dev_out_*.  Query values are
- * not checked for NaN/inf on this path.  Used by the multi-GPU path (local
+ * caller synchronises the stream before reading dev_out_*.  A NaN/inf in the
+ * queries cannot fail a call that does not wait for the GPU: it is recorded, and
+ * mtr_index_nonfinite reports it afterwards.  Used by the multi-GPU path (local
  * candidates feed the all-gather) and by benchmarks. */
 int mtr_index_search_device(mtr_index_t* index, const void* dev_queries, int32_t q_dtype,
                             int32_t b, int32_t k, int32_t metric,
                             int64_t* dev_out_idx, float* dev_out_score, void* stream);
+
+/* Whether the queries of the last mtr_index_search_device call on the handle
+ * held a NaN or infinity (*nonfinite = 1; its results are then meaningless, and
+ * the reference's scorer raises ValueError: pipeline/utils/local_rag.py:77).
+ * Waits for that search to finish. */
+int mtr_index_nonfinite(mtr_index_t* index, int32_t* nonfinite);
 
 /* k-way merge of per-shard candidate lists on GPU device_id: inputs are
  * n_lists blocks of b x k_in (id, score) pairs laid out [list][b][k_in] --
@@ -135,6 +147,16 @@ int mtr_index_scan_time(mtr_index_t* index, int32_t* n_launches, double* total_m
 int mtr_index_scan_samples(mtr_index_t* index, float* out_ms, int32_t cap, int32_t* n_launches);
 
 void mtr_index_destroy(mtr_index_t* index);
+
+/* Process-wide launch-shape switches, for parity tests (which force the
+ * kernel forms of large shards onto small ones) and timing sweeps; not needed
+ * for normal use.  Names: mfma_min_batch, mfma_tnq, mfma_per_cu, mfma_cap,
+ * mfma_sample_stride, mfma_stream_rows, mfma_stages, mfma_tile_rows,
+ * wide_min_batch, scan_wg_per_cu, scan_nontemporal.  Each starts from the
+ * environment variable MTR_<NAME> if set.  Unknown name: MTR_ERR_INVALID.
+ * No counterpart in the reference. */
+int mtr_tuning_set(const char* name, int32_t value);
+int mtr_tuning_get(const char* name, int32_t* value);
 
 /* Thread-local message of the last failing call on this thread ("" if none). */
 const char* mtr_last_error(void);

@@ -32,6 +32,7 @@ SIGNATURES = {
     "mtr_index_create": (_i32, [_vp, _i64, _i32, _i32, _i32, _i32, _i32, _i64, _pp]),
     "mtr_index_search": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "mtr_index_search_device": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "mtr_index_nonfinite": (_i32, [_vp, C.POINTER(_i32)]),
     "mtr_merge_topk_device": (_i32, [_vp, _vp, _i32, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
     "mtr_pool_normalize": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _vp]),
     "mtr_index_info": (_i32, [_vp, C.POINTER(_i64), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32),
@@ -40,6 +41,8 @@ SIGNATURES = {
     "mtr_index_profile": (_i32, [_vp, _i32]),
     "mtr_index_scan_time": (_i32, [_vp, C.POINTER(_i32), C.POINTER(C.c_double)]),
     "mtr_index_scan_samples": (_i32, [_vp, C.POINTER(C.c_float), _i32, C.POINTER(_i32)]),
+    "mtr_tuning_set": (_i32, [C.c_char_p, _i32]),
+    "mtr_tuning_get": (_i32, [C.c_char_p, C.POINTER(_i32)]),
     "mtr_index_destroy": (None, [_vp]),
     "mtr_last_error": (C.c_char_p, []),
     "mtr_version": (C.c_char_p, []),
@@ -93,6 +96,32 @@ def check(rc: int) -> None:
     raise RuntimeError(f"medtutor_retrieval error {rc}: {msg}")
 
 
+def set_option(name: str, value: int) -> int:
+    """Sets a process-wide launch-shape switch (mtr_tuning_set); returns the
+    previous value.  For parity tests and timing sweeps."""
+    old = _i32()
+    check(lib().mtr_tuning_get(name.encode(), C.byref(old)))
+    check(lib().mtr_tuning_set(name.encode(), int(value)))
+    return old.value
+
+
+class options:
+    """Context manager: launch-shape switches set for the enclosed searches."""
+
+    def __init__(self, **values):
+        self._values, self._old = values, {}
+
+    def __enter__(self):
+        for name, value in self._values.items():
+            self._old[name] = set_option(name, value)
+        return self
+
+    def __exit__(self, *exc):
+        for name, value in self._old.items():
+            set_option(name, value)
+        return False
+
+
 def np_dtype_code(a: np.ndarray) -> int:
     if a.dtype == np.float32:
         return MTR_F32
@@ -131,6 +160,7 @@ class DeviceShard:
     def __init__(self, handle, keepalive=None):
         self._h = handle
         self._keep = keepalive
+        self._device = None
 
     # -- construction -------------------------------------------------------
     @classmethod
@@ -175,6 +205,12 @@ class DeviceShard:
                 "normalized": bool(nm.value), "device": dev.value, "row_offset": ro.value}
 
     @property
+    def device(self):
+        if self._device is None:
+            self._device = self.info()["device"]
+        return self._device
+
+    @property
     def n(self):
         return self.info()["n"]
 
@@ -204,18 +240,30 @@ class DeviceShard:
             queries = queries[None, :]
         if not queries.is_cuda or not queries.is_contiguous() or queries.shape[1] != self.d:
             raise ValueError("search_device wants a contiguous (B, d) tensor on the GPU")
+        if queries.device.index != self.device:
+            raise ValueError(f"queries are on {queries.device}, the shard is on GPU {self.device}")
         b = queries.shape[0]
         if out is None:
             idx = torch.empty((b, k), dtype=torch.int64, device=queries.device)
             score = torch.empty((b, k), dtype=torch.float32, device=queries.device)
         else:
             idx, score = out
+            for t, dt in ((idx, torch.int64), (score, torch.float32)):
+                if t.device != queries.device or t.dtype != dt or t.numel() != b * k or not t.is_contiguous():
+                    raise ValueError("out must be contiguous (B, k) int64 / float32 tensors on the shard's GPU")
         if stream is None:
             stream = torch.cuda.current_stream(queries.device).cuda_stream
         check(lib().mtr_index_search_device(self._h, C.c_void_p(queries.data_ptr()), torch_dtype_code(queries), b,
                                             int(k), METRICS[metric], C.c_void_p(idx.data_ptr()),
                                             C.c_void_p(score.data_ptr()), C.c_void_p(stream)))
         return idx, score
+
+    def nonfinite(self) -> bool:
+        """Whether the last search_device call's queries held a NaN or infinity
+        (waits for that search)."""
+        flag = _i32()
+        check(lib().mtr_index_nonfinite(self._h, C.byref(flag)))
+        return bool(flag.value)
 
     def read_rows(self, row_start=0, n_rows=None):
         inf = self.info()

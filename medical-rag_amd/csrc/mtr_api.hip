@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cctype>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -81,6 +82,20 @@ struct DeviceGuard {
 
 }  // namespace
 
+// The device buffers a search needs beyond its inputs and outputs.
+enum ScratchSlot {
+    kQF32,        // padded fp32 queries of one scan pass
+    kCandS,       // per-workgroup / per-range candidate scores ...
+    kCandI,       // ... and rows
+    kQTiles,      // query tiles (storage type) for the matrix-core kernels
+    kMfmaCand,    // the matrix-core kernel's per-workgroup candidate buffers
+    kMfmaFloor,   // per-query floor shared by the row ranges
+    kTileMax,     // the sampling launch's best score per (query, sampled tile)
+    kWideKeys,    // the 256 x 256-tile kernel's key lists ...
+    kWideCounts,  // ... their counts, and one more word: the overflow flag
+    kScratchSlots
+};
+
 struct mtr_index {
     int device = 0;
     int64_t n = 0;
@@ -94,21 +109,21 @@ struct mtr_index {
     int* flag = nullptr;  // device word set by the loader on NaN/inf
     hipStream_t stream = nullptr;
     std::mutex mu;
-    DevBuf q_f32;      // padded fp32 queries of one pass
-    DevBuf q_in;       // staging for host queries
-    DevBuf cand_s, cand_i;
-    DevBuf q_bf16;     // query tiles (storage type) for the matrix-core kernel
-    int64_t q_init_rows = 0;   // its rows [0, q_init_rows) have been written or zeroed at least once ...
+    DevBuf scratch[kScratchSlots];  // grown on demand, kept between searches
+    int64_t q_init_rows = 0;   // rows [0, q_init_rows) of scratch[kQTiles] have been written or zeroed at least once ...
     int64_t q_data_rows = 0;   // ... and only rows [0, q_data_rows) of them can hold non-zero data
-    DevBuf mfma_cand;  // its workgroups' candidate buffers
-    DevBuf mfma_floor; // per-query floor shared by the row ranges
-    DevBuf tile_max;   // the sampling launch's best score per (query, sampled tile)
-    DevBuf wide_keys;  // the 256 x 256-tile kernel's key lists ...
-    DevBuf wide_counts; // ... their counts, and one more word: the overflow flag
+    DevBuf q_in;       // staging for host queries
     DevBuf out_i, out_s;
-    DevBuf stage;      // staging for host rows
-    void* pinned = nullptr;
+    DevBuf stage[2];   // device staging for host rows (two: chunk i+1 is copied while chunk i is converted)
+    void* pinned[2] = {nullptr, nullptr};  // page-locked host staging for the same chunks
     size_t pinned_cap = 0;
+    hipEvent_t stage_done[2] = {nullptr, nullptr};
+    // The scratch buffers are shared by every search on the handle, whatever
+    // stream it is enqueued on: the event marks the end of the last enqueued
+    // work, and work on another stream waits for it first.
+    hipEvent_t last_use = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool used = false;
     // profiling
     bool profiling = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -124,19 +139,45 @@ int check_index(const mtr_index* ix) {
     return MTR_OK;
 }
 
-// Scoring + merge of one batch, enqueued on `stream`.  dev_queries: b x d in
-// q_dtype on the shard's device.  check_flag: leave the loader's non-finite
-// flag set for the caller to read.
+// Where a search takes its scratch buffers from: the handle's own buffers,
+// grown with hipMalloc on demand and kept for the next search.
+struct Scratch {
+    mtr_index* ix = nullptr;
+    void* p[kScratchSlots] = {};
+    int need(ScratchSlot slot, size_t bytes) {
+        int rc = ix->scratch[slot].reserve(bytes);
+        p[slot] = ix->scratch[slot].p;
+        return rc;
+    }
+    int ready() const { return MTR_OK; }
+    // The query-tile buffer keeps its contents between searches, so only rows
+    // never initialised, or holding an earlier, larger batch, need clearing.
+    bool keeps_query_tiles() const { return true; }
+    bool may_profile() const { return true; }
+    bool allows_wide() const { return true; }
+};
+
+// Makes `stream` wait for whatever was last enqueued on the handle from another
+// stream (the scratch buffers, the non-finite flag and the staging buffers are
+// shared), and marks the end of the newly enqueued work.
+int begin_use(mtr_index* ix, hipStream_t stream) {
+    if (ix->used && stream != ix->last_stream) HIP_TRY(hipStreamWaitEvent(stream, ix->last_use, 0));
+    return MTR_OK;
+}
+int end_use(mtr_index* ix, hipStream_t stream) {
+    HIP_TRY(hipEventRecord(ix->last_use, stream));
+    ix->last_stream = stream;
+    ix->used = true;
+    return MTR_OK;
+}
+
 // Smallest batch that goes to the matrix-core kernel; below it the HBM-bound
 // scan handles the batch in passes of up to four queries.  Measured hand-over
 // (1M rows): bf16 x 1024 -- scan 0.33 ms for one query, 0.46 ms for two,
 // matrix cores (32-query tiles) 0.40 ms for two to eight; fp32 x 768 -- scan
 // 0.50 ms for two, 0.80 ms for four, matrix cores (fp32 MFMA) 0.61 ms for three.
 int mfma_min_batch(int dtype) {
-    static const int forced = [] {
-        const char* e = getenv("MTR_MFMA_MIN_BATCH");
-        return e ? atoi(e) : 0;
-    }();
+    const int forced = mtr::tuning().mfma_min_batch;
     if (forced > 0) return forced;
     return dtype == MTR_BF16 ? 2 : 3;
 }
@@ -148,12 +189,8 @@ int mfma_min_batch(int dtype) {
 // tiles (its floor is the k-th largest per-tile best score) and at most
 // kMaxSampleTiles.
 constexpr double kMinTwoPassBytes = 1.0e9;
-int forced_sample_stride() {  // read on every search, so that tests can switch it
-    const char* e = getenv("MTR_MFMA_SAMPLE_STRIDE");
-    return e ? atoi(e) : -1;
-}
 int sample_stride(long long n, long long n_tiles, int k) {
-    const int forced = forced_sample_stride();
+    const int forced = mtr::tuning().mfma_sample_stride;
     long long s = forced >= 0 ? forced : (long long)(std::sqrt((double)n / (double)k) / 5.0);
     if (forced < 0) s = std::min<long long>(1024, std::max<long long>(4, s));
     if (s < 2) return 0;
@@ -162,18 +199,24 @@ int sample_stride(long long n, long long n_tiles, int k) {
     return s >= 2 ? (int)s : 0;
 }
 
-// Smallest batch that goes to the 256 x 256-tile kernel (bf16 shards large
-// enough for a sampling launch); read on every search, so that tests can switch it.
-// Measured on 1M x 1024 rows, k = 10: 128 queries 0.55 ms general / 0.76 ms wide,
-// 192: 0.85 / 0.76, 512: 1.49 / 1.25, 4096: 10.7 / 8.7.
-int wide_min_batch() {
-    const char* e = getenv("MTR_WIDE_MIN_BATCH");
-    return e ? atoi(e) : 129;
+// One event pair of the per-launch profile (created on first use, then reused).
+int next_event_pair(mtr_index* ix, hipEvent_t* e0, hipEvent_t* e1) {
+    if (ix->events_used == ix->events.size()) {
+        hipEvent_t a, c;
+        HIP_TRY(hipEventCreate(&a));
+        HIP_TRY(hipEventCreate(&c));
+        ix->events.emplace_back(a, c);
+    }
+    *e0 = ix->events[ix->events_used].first;
+    *e1 = ix->events[ix->events_used].second;
+    ix->events_used++;
+    return MTR_OK;
 }
 
 // Matrix-core path: queries converted to the shard's type, fused score + top-k
 // launch, then the merge of the per-range lists.
-int enqueue_mfma(mtr_index* ix, const mtr::MfmaPlan& plan, const void* dev_queries, int q_dtype, int b, int k,
+template <typename S>
+int enqueue_mfma(mtr_index* ix, S& sc, const mtr::MfmaPlan& plan, const void* dev_queries, int q_dtype, int b, int k,
                  int metric, long long* dev_out_idx, float* dev_out_score, hipStream_t stream) {
     int rc;
     // Large shards get a sampling launch first: every stride-th row tile is
@@ -183,7 +226,7 @@ int enqueue_mfma(mtr_index* ix, const mtr::MfmaPlan& plan, const void* dev_queri
     // instead of collecting and re-selecting the first tiles of every row range.
     // The extra launches cost about 0.05 ms: not worth it on shards that one
     // launch scores in a few tenths of a ms.
-    const bool big = forced_sample_stride() >= 0 ||
+    const bool big = mtr::tuning().mfma_sample_stride >= 0 ||
                      (double)ix->n * ix->ld * dtype_size(ix->dtype) >= kMinTwoPassBytes;
     // Large batches on bf16 shards: the 256 x 256-tile kernel, first in its
     // sampling form over every wstride-th of ITS tiles (floors and filtered
@@ -194,7 +237,7 @@ int enqueue_mfma(mtr_index* ix, const mtr::MfmaPlan& plan, const void* dev_queri
     mtr::WidePlan wide, wide_samp;
     int wstride = 0;
     bool use_wide = false;
-    if (big && ix->dtype == MTR_BF16 && b >= wide_min_batch()) {
+    if (big && ix->dtype == MTR_BF16 && b >= mtr::tuning().wide_min_batch && sc.allows_wide()) {
         const long long wtiles = (ix->n + 255) / 256;
         wstride = sample_stride(ix->n, wtiles, k);
         if (wstride >= 2) {
@@ -220,104 +263,110 @@ int enqueue_mfma(mtr_index* ix, const mtr::MfmaPlan& plan, const void* dev_queri
     const size_t q_row_bytes = (size_t)ix->ld * dtype_size(ix->dtype);
     const int64_t q_rows = std::max<int64_t>((int64_t)plan.n_qtiles * plan.tnq, use_wide ? (int64_t)wide.n_qtiles * 256 : 0);
     const size_t qbytes = (size_t)q_rows * q_row_bytes;
-    const void* q_before = ix->q_bf16.p;
-    if ((rc = ix->q_bf16.reserve(qbytes)) != MTR_OK) return rc;
-    if (ix->q_bf16.p != q_before) ix->q_init_rows = ix->q_data_rows = 0;
-    if ((rc = ix->mfma_cand.reserve(plan.cand_bytes)) != MTR_OK) return rc;
-    if ((rc = ix->cand_s.reserve((size_t)b * plan.n_ranges * k * 4)) != MTR_OK) return rc;
-    if ((rc = ix->cand_i.reserve((size_t)b * plan.n_ranges * k * 4)) != MTR_OK) return rc;
+    const void* q_old = sc.keeps_query_tiles() ? ix->scratch[kQTiles].p : nullptr;
+    if ((rc = sc.need(kQTiles, qbytes)) != MTR_OK) return rc;
+    if ((rc = sc.need(kMfmaCand, plan.cand_bytes)) != MTR_OK) return rc;
+    if ((rc = sc.need(kCandS, (size_t)b * plan.n_ranges * k * 4)) != MTR_OK) return rc;
+    if ((rc = sc.need(kCandI, (size_t)b * plan.n_ranges * k * 4)) != MTR_OK) return rc;
     const int floor_words = std::max(plan.n_qtiles * plan.tnq, use_wide ? wide.n_qtiles * 256 : 0);
-    if ((rc = ix->mfma_floor.reserve((size_t)floor_words * 4)) != MTR_OK) return rc;
+    if ((rc = sc.need(kMfmaFloor, (size_t)floor_words * 4)) != MTR_OK) return rc;
+    size_t tile_max_bytes = 0;
     if (use_wide) {
-        if ((rc = ix->wide_keys.reserve(wide.key_bytes)) != MTR_OK) return rc;
-        if ((rc = ix->wide_counts.reserve((wide.count_words + 1) * 4)) != MTR_OK) return rc;
-        if ((rc = ix->tile_max.reserve((size_t)wide.n_qtiles * 256 * wide_samp.n_tiles * 4)) != MTR_OK) return rc;
+        if ((rc = sc.need(kWideKeys, wide.key_bytes)) != MTR_OK) return rc;
+        if ((rc = sc.need(kWideCounts, (wide.count_words + 1) * 4)) != MTR_OK) return rc;
+        tile_max_bytes = (size_t)wide.n_qtiles * 256 * wide_samp.n_tiles * 4;
     }
-    if (stride >= 2 && (rc = ix->tile_max.reserve((size_t)floor_words * samp.n_tiles * 4)) != MTR_OK) return rc;
+    if (stride >= 2) tile_max_bytes = std::max<size_t>(tile_max_bytes, (size_t)floor_words * (size_t)samp.n_tiles * 4);
+    if (tile_max_bytes && (rc = sc.need(kTileMax, tile_max_bytes)) != MTR_OK) return rc;
+    if ((rc = sc.ready()) != MTR_OK) return rc;
     // A sampling launch's floor kernel sets every real query's floor; otherwise they start from zero.
-    if (stride < 2) HIP_TRY(hipMemsetAsync(ix->mfma_floor.p, 0, (size_t)floor_words * 4, stream));
-    // Query rows past b must be zero.  The buffer keeps its contents between
-    // searches, so only rows never initialised, or holding an earlier, larger
-    // batch, are cleared: nothing in the steady state of equal batch sizes.
-    char* qbuf = static_cast<char*>(ix->q_bf16.p);
-    if (q_rows > ix->q_init_rows) {
-        HIP_TRY(hipMemsetAsync(qbuf + (size_t)ix->q_init_rows * q_row_bytes, 0,
-                               (size_t)(q_rows - ix->q_init_rows) * q_row_bytes, stream));
-        ix->q_init_rows = q_rows;
+    if (stride < 2) HIP_TRY(hipMemsetAsync(sc.p[kMfmaFloor], 0, (size_t)floor_words * 4, stream));
+    // Query rows past b must be zero.
+    char* qbuf = static_cast<char*>(sc.p[kQTiles]);
+    if (sc.keeps_query_tiles()) {
+        if (sc.p[kQTiles] != q_old) ix->q_init_rows = ix->q_data_rows = 0;
+        if (q_rows > ix->q_init_rows) {
+            HIP_TRY(hipMemsetAsync(qbuf + (size_t)ix->q_init_rows * q_row_bytes, 0,
+                                   (size_t)(q_rows - ix->q_init_rows) * q_row_bytes, stream));
+            ix->q_init_rows = q_rows;
+        }
+        if (ix->q_data_rows > b)
+            HIP_TRY(hipMemsetAsync(qbuf + (size_t)b * q_row_bytes, 0, (size_t)(ix->q_data_rows - b) * q_row_bytes, stream));
+        ix->q_data_rows = b;
+    } else if (q_rows > b) {
+        HIP_TRY(hipMemsetAsync(qbuf + (size_t)b * q_row_bytes, 0, (size_t)(q_rows - b) * q_row_bytes, stream));
     }
-    if (ix->q_data_rows > b)
-        HIP_TRY(hipMemsetAsync(qbuf + (size_t)b * q_row_bytes, 0, (size_t)(ix->q_data_rows - b) * q_row_bytes, stream));
-    ix->q_data_rows = b;
-    HIP_TRY(mtr::launch_load_rows(dev_queries, q_dtype, b, ix->d, ix->q_bf16.p, ix->dtype, ix->ld,
+    HIP_TRY(mtr::launch_load_rows(dev_queries, q_dtype, b, ix->d, qbuf, ix->dtype, ix->ld,
                                   metric == MTR_COSINE ? 1 : 0, ix->flag, stream));
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (ix->profiling) {
-        if (ix->events_used == ix->events.size()) {
-            hipEvent_t a, c;
-            HIP_TRY(hipEventCreate(&a));
-            HIP_TRY(hipEventCreate(&c));
-            ix->events.emplace_back(a, c);
-        }
-        e0 = ix->events[ix->events_used].first;
-        e1 = ix->events[ix->events_used].second;
-        ix->events_used++;
+    const bool profiling = ix->profiling && sc.may_profile();
+    if (profiling) {
+        if ((rc = next_event_pair(ix, &e0, &e1)) != MTR_OK) return rc;
         HIP_TRY(hipEventRecord(e0, stream));
     }
-    unsigned int* floors = static_cast<unsigned int*>(ix->mfma_floor.p);
-    float* lists_s = static_cast<float*>(ix->cand_s.p);
-    int* lists_i = static_cast<int*>(ix->cand_i.p);
+    unsigned int* floors = static_cast<unsigned int*>(sc.p[kMfmaFloor]);
+    float* lists_s = static_cast<float*>(sc.p[kCandS]);
+    int* lists_i = static_cast<int*>(sc.p[kCandI]);
     if (stride >= 2) {
-        unsigned int* tile_max = static_cast<unsigned int*>(ix->tile_max.p);
+        unsigned int* tile_max = static_cast<unsigned int*>(sc.p[kTileMax]);
         const mtr::MfmaPass sampling{stride, tile_max, nullptr};
-        HIP_TRY(mtr::launch_score_mfma(ix->rows, ix->dtype, ix->n, ix->ld, ix->q_bf16.p, b, k, samp, sampling,
-                                       ix->mfma_cand.p, floors, lists_s, lists_i, stream));
+        HIP_TRY(mtr::launch_score_mfma(ix->rows, ix->dtype, ix->n, ix->ld, qbuf, b, k, samp, sampling,
+                                       sc.p[kMfmaCand], floors, lists_s, lists_i, stream));
         HIP_TRY(mtr::launch_floor_from_tile_max(tile_max, (int)samp.n_tiles, b, k, floors, stream));
     }
     int* overflow = nullptr;
     if (use_wide) {
-        unsigned int* counts = static_cast<unsigned int*>(ix->wide_counts.p);
-        unsigned long long* keys = static_cast<unsigned long long*>(ix->wide_keys.p);
-        unsigned int* tile_max = static_cast<unsigned int*>(ix->tile_max.p);
+        unsigned int* counts = static_cast<unsigned int*>(sc.p[kWideCounts]);
+        unsigned long long* keys = static_cast<unsigned long long*>(sc.p[kWideKeys]);
+        unsigned int* tile_max = static_cast<unsigned int*>(sc.p[kTileMax]);
         overflow = reinterpret_cast<int*>(counts + wide.count_words);
         HIP_TRY(hipMemsetAsync(overflow, 0, 4, stream));
         // the sampling form raises tile_max with atomic maxima: every word starts at zero (below any score)
         HIP_TRY(hipMemsetAsync(tile_max, 0, (size_t)wide.n_qtiles * 256 * wide_samp.n_tiles * 4, stream));
-        HIP_TRY(mtr::launch_score_wide(ix->rows, ix->n, ix->ld, ix->q_bf16.p, b, wide_samp, nullptr, nullptr, nullptr, wstride,
+        HIP_TRY(mtr::launch_score_wide(ix->rows, ix->n, ix->ld, qbuf, b, wide_samp, nullptr, nullptr, nullptr, wstride,
                                        tile_max, stream));
         HIP_TRY(mtr::launch_floor_from_tile_max(tile_max, (int)wide_samp.n_tiles, b, k, floors, stream));
-        HIP_TRY(mtr::launch_score_wide(ix->rows, ix->n, ix->ld, ix->q_bf16.p, b, wide, floors, keys, counts, 1, nullptr, stream));
-        if (ix->profiling) HIP_TRY(hipEventRecord(e1, stream));
+        HIP_TRY(mtr::launch_score_wide(ix->rows, ix->n, ix->ld, qbuf, b, wide, floors, keys, counts, 1, nullptr, stream));
+        if (profiling) HIP_TRY(hipEventRecord(e1, stream));
         HIP_TRY(mtr::launch_select_keys(keys, counts, wide.n_lists * mtr::kWideSubs, mtr::kWideSubs, wide.cap, (int)ix->n, b, k, ix->row_offset, dev_out_idx,
                                         dev_out_score, overflow, stream));
         HIP_TRY(mtr::launch_reset_floors_if(floors, floor_words, overflow, stream));
     }
     const mtr::MfmaPass all{1, nullptr, overflow};
-    HIP_TRY(mtr::launch_score_mfma(ix->rows, ix->dtype, ix->n, ix->ld, ix->q_bf16.p, b, k, plan, all, ix->mfma_cand.p,
+    HIP_TRY(mtr::launch_score_mfma(ix->rows, ix->dtype, ix->n, ix->ld, qbuf, b, k, plan, all, sc.p[kMfmaCand],
                                    floors, lists_s, lists_i, stream));
-    if (ix->profiling && !use_wide) HIP_TRY(hipEventRecord(e1, stream));
+    if (profiling && !use_wide) HIP_TRY(hipEventRecord(e1, stream));
     HIP_TRY(mtr::launch_merge_topk(lists_s, lists_i, nullptr, plan.n_ranges, (long long)k, (long long)k,
                                    (long long)plan.n_ranges * k, k, b, k, ix->row_offset, dev_out_idx, dev_out_score,
                                    stream, overflow));
     return MTR_OK;
 }
 
-int enqueue_search(mtr_index* ix, const void* dev_queries, int q_dtype, int b, int k, int metric,
+// Scoring + merge of one batch, enqueued on `stream`.  dev_queries: b x d in
+// q_dtype on the shard's device.
+template <typename S>
+int enqueue_search(mtr_index* ix, S& sc, const void* dev_queries, int q_dtype, int b, int k, int metric,
                    long long* dev_out_idx, float* dev_out_score, hipStream_t stream) {
     if (metric == MTR_COSINE && !ix->normalized)
         return fail(MTR_ERR_INVALID, "cosine search needs a shard built with normalize=1");
     if (b >= mfma_min_batch(ix->dtype)) {
         mtr::MfmaPlan mplan;
         if (mtr::plan_mfma(ix->dtype, ix->n, ix->ld, b, k, ix->num_cus, 0, &mplan) == 0)
-            return enqueue_mfma(ix, mplan, dev_queries, q_dtype, b, k, metric, dev_out_idx, dev_out_score, stream);
+            return enqueue_mfma(ix, sc, mplan, dev_queries, q_dtype, b, k, metric, dev_out_idx, dev_out_score, stream);
     }
     mtr::ScanPlan plan;
     if (mtr::plan_scan(ix->dtype, ix->n, ix->d, ix->ld, b, k, ix->num_cus, &plan) != 0)
         return fail(MTR_ERR_INVALID, "unsupported search shape (d=%d, k=%d)", ix->d, k);
     int rc;
-    if ((rc = ix->q_f32.reserve((size_t)plan.qb * plan.qstride * 4)) != MTR_OK) return rc;
-    if ((rc = ix->cand_s.reserve((size_t)plan.qb * plan.grid * k * 4)) != MTR_OK) return rc;
-    if ((rc = ix->cand_i.reserve((size_t)plan.qb * plan.grid * k * 4)) != MTR_OK) return rc;
+    if ((rc = sc.need(kQF32, (size_t)plan.qb * plan.qstride * 4)) != MTR_OK) return rc;
+    if ((rc = sc.need(kCandS, (size_t)plan.qb * plan.grid * k * 4)) != MTR_OK) return rc;
+    if ((rc = sc.need(kCandI, (size_t)plan.qb * plan.grid * k * 4)) != MTR_OK) return rc;
+    if ((rc = sc.ready()) != MTR_OK) return rc;
+    float* q_f32 = static_cast<float*>(sc.p[kQF32]);
+    float* cand_s = static_cast<float*>(sc.p[kCandS]);
+    int* cand_i = static_cast<int*>(sc.p[kCandI]);
     const int qsize = dtype_size(q_dtype);
+    const bool profiling = ix->profiling && sc.may_profile();
     for (int b0 = 0; b0 < b; b0 += plan.qb) {
         const int nb = std::min(plan.qb, b - b0);
         // fp32 queries are normalised and padded inside the scan kernel; other
@@ -326,33 +375,36 @@ int enqueue_search(mtr_index* ix, const void* dev_queries, int q_dtype, int b, i
         const char* qsrc = static_cast<const char*>(dev_queries) + (size_t)b0 * ix->d * qsize;
         const bool raw = q_dtype == MTR_F32;
         if (!raw) {
-            if (nb < plan.qb) HIP_TRY(hipMemsetAsync(ix->q_f32.p, 0, (size_t)plan.qb * plan.qstride * 4, stream));
-            HIP_TRY(mtr::launch_load_rows(qsrc, q_dtype, nb, ix->d, ix->q_f32.p, MTR_F32, plan.qstride,
+            if (nb < plan.qb) HIP_TRY(hipMemsetAsync(q_f32, 0, (size_t)plan.qb * plan.qstride * 4, stream));
+            HIP_TRY(mtr::launch_load_rows(qsrc, q_dtype, nb, ix->d, q_f32, MTR_F32, plan.qstride,
                                           metric == MTR_COSINE ? 1 : 0, ix->flag, stream));
         }
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (ix->profiling) {
-            if (ix->events_used == ix->events.size()) {
-                hipEvent_t a, c;
-                HIP_TRY(hipEventCreate(&a));
-                HIP_TRY(hipEventCreate(&c));
-                ix->events.emplace_back(a, c);
-            }
-            e0 = ix->events[ix->events_used].first;
-            e1 = ix->events[ix->events_used].second;
-            ix->events_used++;
+        if (profiling) {
+            if ((rc = next_event_pair(ix, &e0, &e1)) != MTR_OK) return rc;
             HIP_TRY(hipEventRecord(e0, stream));
         }
-        HIP_TRY(mtr::launch_scan_topk(ix->rows, ix->dtype, ix->n, ix->ld, ix->d, static_cast<const float*>(ix->q_f32.p),
+        HIP_TRY(mtr::launch_scan_topk(ix->rows, ix->dtype, ix->n, ix->ld, ix->d, q_f32,
                                       raw ? reinterpret_cast<const float*>(qsrc) : nullptr, nb,
-                                      metric == MTR_COSINE ? 1 : 0, ix->flag, k, plan, static_cast<float*>(ix->cand_s.p), static_cast<int*>(ix->cand_i.p),
-                                      stream));
-        if (ix->profiling) HIP_TRY(hipEventRecord(e1, stream));
+                                      metric == MTR_COSINE ? 1 : 0, ix->flag, k, plan, cand_s, cand_i, stream));
+        if (profiling) HIP_TRY(hipEventRecord(e1, stream));
         // the scan's per-workgroup lists are sorted best first
-        HIP_TRY(mtr::launch_merge_sorted_lists(static_cast<const float*>(ix->cand_s.p), static_cast<const int*>(ix->cand_i.p),
-                                               plan.grid, (long long)k, (long long)plan.grid * k, k, nb, k, ix->row_offset,
-                                               dev_out_idx + (size_t)b0 * k, dev_out_score + (size_t)b0 * k, stream));
+        HIP_TRY(mtr::launch_merge_sorted_lists(cand_s, cand_i, plan.grid, (long long)k, (long long)plan.grid * k, k, nb, k,
+                                               ix->row_offset, dev_out_idx + (size_t)b0 * k, dev_out_score + (size_t)b0 * k,
+                                               stream));
     }
+    return MTR_OK;
+}
+
+int check_search_args(const mtr_index* ix, const void* queries, const void* out_idx, const void* out_score, int q_dtype,
+                      int b, int k, int metric) {
+    int rc = check_index(ix);
+    if (rc != MTR_OK) return rc;
+    if (!queries || !out_idx || !out_score) return fail(MTR_ERR_INVALID, "NULL argument");
+    if (b < 1) return fail(MTR_ERR_INVALID, "b must be >= 1");
+    if (k < 1 || k > MTR_MAX_K) return fail(MTR_ERR_INVALID, "k must be in [1, %d]", MTR_MAX_K);
+    if (metric != MTR_COSINE && metric != MTR_IP) return fail(MTR_ERR_INVALID, "bad metric %d", metric);
+    if (!dtype_size(q_dtype)) return fail(MTR_ERR_INVALID, "bad q_dtype %d", q_dtype);
     return MTR_OK;
 }
 
@@ -398,6 +450,7 @@ int mtr_index_alloc(int64_t n, int32_t d, int32_t store_dtype, int32_t normalize
     e = hipMalloc(reinterpret_cast<void**>(&ix->flag), 256);
     if (e == hipSuccess) e = hipMemset(ix->flag, 0, 256);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ix->last_use, hipEventDisableTiming);
     if (e != hipSuccess) {
         mtr_index_destroy(ix);
         return fail(MTR_ERR_HIP, "shard set-up: %s", hipGetErrorString(e));
@@ -405,6 +458,47 @@ int mtr_index_alloc(int64_t n, int32_t d, int32_t store_dtype, int32_t normalize
     *out = ix;
     return MTR_OK;
 }
+
+namespace {
+
+// Host rows -> shard through page-locked staging: the host copy of chunk i + 1
+// into its pinned buffer runs while chunk i crosses PCIe and is converted.
+int upload_host_rows(mtr_index* ix, int64_t row_start, const char* rows, int64_t n_rows, int src_dtype) {
+    int rc;
+    const size_t esize = dtype_size(ix->dtype);
+    const size_t src_row = (size_t)ix->d * dtype_size(src_dtype);
+    const int64_t chunk_rows = std::max<int64_t>(1, (int64_t)(kStageBytes / src_row));
+    const size_t chunk_bytes = (size_t)std::min(chunk_rows, n_rows) * src_row;
+    const int n_buf = n_rows > chunk_rows ? 2 : 1;
+    if (ix->pinned_cap < chunk_bytes) {
+        for (int i = 0; i < 2; ++i) {
+            if (ix->pinned[i]) (void)hipHostFree(ix->pinned[i]);
+            ix->pinned[i] = nullptr;
+        }
+        ix->pinned_cap = 0;
+    }
+    for (int i = 0; i < n_buf; ++i) {
+        if ((rc = ix->stage[i].reserve(chunk_bytes)) != MTR_OK) return rc;
+        if (!ix->pinned[i]) HIP_TRY(hipHostMalloc(&ix->pinned[i], std::max(chunk_bytes, ix->pinned_cap), hipHostMallocDefault));
+        if (!ix->stage_done[i]) HIP_TRY(hipEventCreateWithFlags(&ix->stage_done[i], hipEventDisableTiming));
+    }
+    ix->pinned_cap = std::max(chunk_bytes, ix->pinned_cap);
+    int64_t chunk = 0;
+    for (int64_t r0 = 0; r0 < n_rows; r0 += chunk_rows, ++chunk) {
+        const int i = (int)(chunk & 1);
+        const int64_t nr = std::min(chunk_rows, n_rows - r0);
+        if (chunk >= 2) HIP_TRY(hipEventSynchronize(ix->stage_done[i]));   // the buffers' previous chunk is in the shard
+        memcpy(ix->pinned[i], rows + (size_t)r0 * src_row, (size_t)nr * src_row);
+        HIP_TRY(hipMemcpyAsync(ix->stage[i].p, ix->pinned[i], (size_t)nr * src_row, hipMemcpyHostToDevice, ix->stream));
+        char* dst = static_cast<char*>(ix->rows) + (size_t)(row_start + r0) * ix->ld * esize;
+        HIP_TRY(mtr::launch_load_rows(ix->stage[i].p, src_dtype, nr, ix->d, dst, ix->dtype, ix->ld, ix->normalized,
+                                      ix->flag, ix->stream));
+        HIP_TRY(hipEventRecord(ix->stage_done[i], ix->stream));
+    }
+    return MTR_OK;
+}
+
+}  // namespace
 
 int mtr_index_load_rows(mtr_index_t* ix, int64_t row_start, const void* rows, int64_t n_rows, int32_t src_dtype,
                         int32_t rows_on_device) {
@@ -418,29 +512,21 @@ int mtr_index_load_rows(mtr_index_t* ix, int64_t row_start, const void* rows, in
                     (long long)(row_start + n_rows), (long long)ix->n);
     std::lock_guard<std::mutex> lock(ix->mu);
     DeviceGuard guard(ix->device);
-    const size_t esize = dtype_size(ix->dtype);
-    const size_t src_row = (size_t)ix->d * ssize;
+    if ((rc = begin_use(ix, ix->stream)) != MTR_OK) return rc;
     HIP_TRY(hipMemsetAsync(ix->flag, 0, 4, ix->stream));
-    if (rows_on_device) {
-        char* dst = static_cast<char*>(ix->rows) + (size_t)row_start * ix->ld * esize;
+    if (n_rows == 0) {
+        // nothing to convert
+    } else if (rows_on_device) {
+        char* dst = static_cast<char*>(ix->rows) + (size_t)row_start * ix->ld * dtype_size(ix->dtype);
         HIP_TRY(mtr::launch_load_rows(rows, src_dtype, n_rows, ix->d, dst, ix->dtype, ix->ld, ix->normalized, ix->flag,
                                       ix->stream));
-    } else {
-        int64_t chunk_rows = std::max<int64_t>(1, (int64_t)(kStageBytes / src_row));
-        if ((rc = ix->stage.reserve((size_t)std::min(chunk_rows, n_rows) * src_row)) != MTR_OK) return rc;
-        for (int64_t r0 = 0; r0 < n_rows; r0 += chunk_rows) {
-            const int64_t nr = std::min(chunk_rows, n_rows - r0);
-            HIP_TRY(hipMemcpyAsync(ix->stage.p, static_cast<const char*>(rows) + (size_t)r0 * src_row,
-                                   (size_t)nr * src_row, hipMemcpyHostToDevice, ix->stream));
-            char* dst = static_cast<char*>(ix->rows) + (size_t)(row_start + r0) * ix->ld * esize;
-            HIP_TRY(mtr::launch_load_rows(ix->stage.p, src_dtype, nr, ix->d, dst, ix->dtype, ix->ld, ix->normalized,
-                                          ix->flag, ix->stream));
-            // the staging buffer is reused by the next chunk
-            HIP_TRY(hipStreamSynchronize(ix->stream));
-        }
+    } else if ((rc = upload_host_rows(ix, row_start, static_cast<const char*>(rows), n_rows, src_dtype)) != MTR_OK) {
+        (void)hipStreamSynchronize(ix->stream);
+        return rc;
     }
     int flag = 0;
     HIP_TRY(hipMemcpyAsync(&flag, ix->flag, 4, hipMemcpyDeviceToHost, ix->stream));
+    if ((rc = end_use(ix, ix->stream)) != MTR_OK) return rc;
     HIP_TRY(hipStreamSynchronize(ix->stream));
     if (flag) return fail(MTR_ERR_NONFINITE, "Input contains NaN or infinity.");
     return MTR_OK;
@@ -462,19 +548,14 @@ int mtr_index_create(const void* host_rows, int64_t n, int32_t d, int32_t src_dt
 
 int mtr_index_search(mtr_index_t* ix, const void* queries, int32_t q_dtype, int32_t queries_on_device, int32_t b,
                      int32_t k, int32_t metric, int64_t* out_idx, float* out_score) {
-    int rc = check_index(ix);
+    int rc = check_search_args(ix, queries, out_idx, out_score, q_dtype, b, k, metric);
     if (rc != MTR_OK) return rc;
-    if (!queries || !out_idx || !out_score) return fail(MTR_ERR_INVALID, "NULL argument");
-    if (b < 1) return fail(MTR_ERR_INVALID, "b must be >= 1");
-    if (k < 1 || k > MTR_MAX_K) return fail(MTR_ERR_INVALID, "k must be in [1, %d]", MTR_MAX_K);
-    if (metric != MTR_COSINE && metric != MTR_IP) return fail(MTR_ERR_INVALID, "bad metric %d", metric);
-    const int qsize = dtype_size(q_dtype);
-    if (!qsize) return fail(MTR_ERR_INVALID, "bad q_dtype %d", q_dtype);
     std::lock_guard<std::mutex> lock(ix->mu);
     DeviceGuard guard(ix->device);
+    if ((rc = begin_use(ix, ix->stream)) != MTR_OK) return rc;
     const void* dq = queries;
     if (!queries_on_device) {
-        const size_t bytes = (size_t)b * ix->d * qsize;
+        const size_t bytes = (size_t)b * ix->d * dtype_size(q_dtype);
         if ((rc = ix->q_in.reserve(bytes)) != MTR_OK) return rc;
         HIP_TRY(hipMemcpyAsync(ix->q_in.p, queries, bytes, hipMemcpyHostToDevice, ix->stream));
         dq = ix->q_in.p;
@@ -482,16 +563,22 @@ int mtr_index_search(mtr_index_t* ix, const void* queries, int32_t q_dtype, int3
     if ((rc = ix->out_i.reserve((size_t)b * k * 8)) != MTR_OK) return rc;
     if ((rc = ix->out_s.reserve((size_t)b * k * 4)) != MTR_OK) return rc;
     HIP_TRY(hipMemsetAsync(ix->flag, 0, 4, ix->stream));
-    rc = enqueue_search(ix, dq, q_dtype, b, k, metric, static_cast<long long*>(ix->out_i.p),
+    Scratch sc;
+    sc.ix = ix;
+    rc = enqueue_search(ix, sc, dq, q_dtype, b, k, metric, static_cast<long long*>(ix->out_i.p),
                         static_cast<float*>(ix->out_s.p), ix->stream);
     if (rc != MTR_OK) {
+        std::string keep = g_err;
+        (void)end_use(ix, ix->stream);
         (void)hipStreamSynchronize(ix->stream);
+        g_err = keep;
         return rc;
     }
     int flag = 0;
     HIP_TRY(hipMemcpyAsync(out_idx, ix->out_i.p, (size_t)b * k * 8, hipMemcpyDeviceToHost, ix->stream));
     HIP_TRY(hipMemcpyAsync(out_score, ix->out_s.p, (size_t)b * k * 4, hipMemcpyDeviceToHost, ix->stream));
     HIP_TRY(hipMemcpyAsync(&flag, ix->flag, 4, hipMemcpyDeviceToHost, ix->stream));
+    if ((rc = end_use(ix, ix->stream)) != MTR_OK) return rc;
     HIP_TRY(hipStreamSynchronize(ix->stream));
     if (flag) return fail(MTR_ERR_NONFINITE, "Input contains NaN or infinity.");
     return MTR_OK;
@@ -499,18 +586,34 @@ int mtr_index_search(mtr_index_t* ix, const void* queries, int32_t q_dtype, int3
 
 int mtr_index_search_device(mtr_index_t* ix, const void* dev_queries, int32_t q_dtype, int32_t b, int32_t k,
                             int32_t metric, int64_t* dev_out_idx, float* dev_out_score, void* stream) {
-    int rc = check_index(ix);
+    int rc = check_search_args(ix, dev_queries, dev_out_idx, dev_out_score, q_dtype, b, k, metric);
     if (rc != MTR_OK) return rc;
-    if (!dev_queries || !dev_out_idx || !dev_out_score) return fail(MTR_ERR_INVALID, "NULL argument");
-    if (b < 1) return fail(MTR_ERR_INVALID, "b must be >= 1");
-    if (k < 1 || k > MTR_MAX_K) return fail(MTR_ERR_INVALID, "k must be in [1, %d]", MTR_MAX_K);
-    if (metric != MTR_COSINE && metric != MTR_IP) return fail(MTR_ERR_INVALID, "bad metric %d", metric);
-    if (!dtype_size(q_dtype)) return fail(MTR_ERR_INVALID, "bad q_dtype %d", q_dtype);
     std::lock_guard<std::mutex> lock(ix->mu);
     DeviceGuard guard(ix->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    return enqueue_search(ix, dev_queries, q_dtype, b, k, metric, reinterpret_cast<long long*>(dev_out_idx),
-                          dev_out_score, s);
+    if ((rc = begin_use(ix, s)) != MTR_OK) return rc;
+    HIP_TRY(hipMemsetAsync(ix->flag, 0, 4, s));
+    Scratch sc;
+    sc.ix = ix;
+    rc = enqueue_search(ix, sc, dev_queries, q_dtype, b, k, metric, reinterpret_cast<long long*>(dev_out_idx),
+                        dev_out_score, s);
+    std::string keep = g_err;
+    const int rc2 = end_use(ix, s);
+    if (rc != MTR_OK) g_err = keep;
+    return rc != MTR_OK ? rc : rc2;
+}
+
+int mtr_index_nonfinite(mtr_index_t* ix, int32_t* nonfinite) {
+    int rc = check_index(ix);
+    if (rc != MTR_OK) return rc;
+    if (!nonfinite) return fail(MTR_ERR_INVALID, "nonfinite is NULL");
+    std::lock_guard<std::mutex> lock(ix->mu);
+    DeviceGuard guard(ix->device);
+    if (ix->used) HIP_TRY(hipEventSynchronize(ix->last_use));
+    int flag = 0;
+    HIP_TRY(hipMemcpy(&flag, ix->flag, 4, hipMemcpyDeviceToHost));
+    *nonfinite = flag ? 1 : 0;
+    return MTR_OK;
 }
 
 int mtr_merge_topk_device(const int64_t* dev_idx, const float* dev_score, int32_t n_lists, int64_t idx_list_stride,
@@ -566,10 +669,12 @@ int mtr_index_read_rows(mtr_index_t* ix, int64_t row_start, int64_t n_rows, floa
     std::lock_guard<std::mutex> lock(ix->mu);
     DeviceGuard guard(ix->device);
     const size_t bytes = (size_t)n_rows * ix->d * 4;
-    if ((rc = ix->stage.reserve(bytes)) != MTR_OK) return rc;
+    if ((rc = ix->stage[0].reserve(bytes)) != MTR_OK) return rc;
+    if ((rc = begin_use(ix, ix->stream)) != MTR_OK) return rc;
     const char* src = static_cast<const char*>(ix->rows) + (size_t)row_start * ix->ld * dtype_size(ix->dtype);
-    HIP_TRY(mtr::launch_read_rows(src, ix->dtype, n_rows, ix->d, ix->ld, static_cast<float*>(ix->stage.p), ix->stream));
-    HIP_TRY(hipMemcpyAsync(host_out, ix->stage.p, bytes, hipMemcpyDeviceToHost, ix->stream));
+    HIP_TRY(mtr::launch_read_rows(src, ix->dtype, n_rows, ix->d, ix->ld, static_cast<float*>(ix->stage[0].p), ix->stream));
+    HIP_TRY(hipMemcpyAsync(host_out, ix->stage[0].p, bytes, hipMemcpyDeviceToHost, ix->stream));
+    if ((rc = end_use(ix, ix->stream)) != MTR_OK) return rc;
     HIP_TRY(hipStreamSynchronize(ix->stream));
     return MTR_OK;
 }
@@ -618,24 +723,22 @@ void mtr_index_destroy(mtr_index_t* ix) {
     if (!ix) return;
     {
         DeviceGuard guard(ix->device);
+        if (ix->used) (void)hipEventSynchronize(ix->last_use);
         if (ix->stream) (void)hipStreamSynchronize(ix->stream);
         for (auto& ev : ix->events) {
             (void)hipEventDestroy(ev.first);
             (void)hipEventDestroy(ev.second);
         }
-        ix->q_f32.release();
+        for (auto& buf : ix->scratch) buf.release();
         ix->q_in.release();
-        ix->cand_s.release();
-        ix->cand_i.release();
-        ix->q_bf16.release();
-        ix->mfma_cand.release();
-        ix->mfma_floor.release();
-        ix->tile_max.release();
-        ix->wide_keys.release();
-        ix->wide_counts.release();
         ix->out_i.release();
         ix->out_s.release();
-        ix->stage.release();
+        for (int i = 0; i < 2; ++i) {
+            ix->stage[i].release();
+            if (ix->pinned[i]) (void)hipHostFree(ix->pinned[i]);
+            if (ix->stage_done[i]) (void)hipEventDestroy(ix->stage_done[i]);
+        }
+        if (ix->last_use) (void)hipEventDestroy(ix->last_use);
         if (ix->flag) (void)hipFree(ix->flag);
         if (ix->rows) (void)hipFree(ix->rows);
         if (ix->stream) (void)hipStreamDestroy(ix->stream);
@@ -643,4 +746,64 @@ void mtr_index_destroy(mtr_index_t* ix) {
     delete ix;
 }
 
+// ---- launch-shape switches ---------------------------------------------------
+
+namespace {
+struct TuningField {
+    const char* name;
+    int mtr::Tuning::*field;
+};
+const TuningField kTuningFields[] = {
+    {"mfma_min_batch", &mtr::Tuning::mfma_min_batch},     {"mfma_tnq", &mtr::Tuning::mfma_tnq},
+    {"mfma_per_cu", &mtr::Tuning::mfma_per_cu},           {"mfma_cap", &mtr::Tuning::mfma_cap},
+    {"mfma_sample_stride", &mtr::Tuning::mfma_sample_stride}, {"mfma_stream_rows", &mtr::Tuning::mfma_stream_rows},
+    {"mfma_stages", &mtr::Tuning::mfma_stages},           {"mfma_tile_rows", &mtr::Tuning::mfma_tile_rows},
+    {"wide_min_batch", &mtr::Tuning::wide_min_batch},     {"scan_wg_per_cu", &mtr::Tuning::scan_wg_per_cu},
+    {"scan_nontemporal", &mtr::Tuning::scan_nontemporal},
+#ifdef MTR_TIMING_SWITCHES
+    {"timing_mfma", &mtr::Tuning::timing_mfma},           {"timing_wide", &mtr::Tuning::timing_wide},
+#endif
+};
+}  // namespace
+
+int mtr_tuning_set(const char* name, int32_t value) {
+    if (!name) return fail(MTR_ERR_INVALID, "name is NULL");
+    for (const TuningField& f : kTuningFields)
+        if (strcmp(name, f.name) == 0) {
+            mtr::tuning().*(f.field) = value;
+            return MTR_OK;
+        }
+    return fail(MTR_ERR_INVALID, "no launch-shape switch named '%s'", name);
+}
+
+int mtr_tuning_get(const char* name, int32_t* value) {
+    if (!name || !value) return fail(MTR_ERR_INVALID, "NULL argument");
+    for (const TuningField& f : kTuningFields)
+        if (strcmp(name, f.name) == 0) {
+            *value = mtr::tuning().*(f.field);
+            return MTR_OK;
+        }
+    return fail(MTR_ERR_INVALID, "no launch-shape switch named '%s'", name);
+}
+
 }  // extern "C"
+
+namespace mtr {
+// Initial values: one environment variable per switch (MTR_ + the upper-case
+// name), read once.
+Tuning& tuning() {
+    static Tuning t = [] {
+        Tuning v;
+        for (const TuningField& f : kTuningFields) {
+            std::string env = "MTR_";
+            for (const char* c = f.name; *c; ++c) env.push_back((char)toupper((unsigned char)*c));
+            if (const char* e = getenv(env.c_str())) v.*(f.field) = atoi(e);
+        }
+#ifdef MTR_TIMING_SWITCHES
+        if (const char* e = getenv("MTR_TIMING_FLOOR")) v.timing_floor = (float)atof(e);
+#endif
+        return v;
+    }();
+    return t;
+}
+}  // namespace mtr

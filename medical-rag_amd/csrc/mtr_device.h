@@ -39,6 +39,31 @@ template <> struct Chunk<bf16_t> {
     }
 };
 
+// ---- launch-shape switches ---------------------------------------------------
+// Process-wide overrides of the launch-shape rules, for parity tests (which
+// force the large-shard kernel forms onto small shards) and timing sweeps.
+// Initial values come from the environment (MTR_MFMA_MIN_BATCH, ... one
+// variable per field, upper case) when the library is first used;
+// mtr_tuning_set changes them afterwards.  No value changes a result beyond
+// what the kernels' parity tests allow.
+struct Tuning {
+    int mfma_min_batch = 0;       // smallest batch on the matrix cores (0: 2 for bf16, 3 for fp32 shards)
+    int mfma_tnq = 0;             // query-tile width 32 / 64 / 128 (0: by batch size)
+    int mfma_per_cu = 0;          // workgroups per CU (0: measured best per form)
+    int mfma_cap = 0;             // candidate slots per (workgroup, query) 256 / 512 (0: by k)
+    int mfma_sample_stride = -1;  // -1: sampling launch on shards >= 1 GB with the sqrt rule; 0: never; n: every n-th tile, any shard
+    int mfma_stream_rows = -1;    // -1: streaming row loads when one query tile reads a shard beyond the caches; 0 / 1
+    int mfma_stages = 0;          // LDS stage buffers 2 / 3 (0: by form)
+    int mfma_tile_rows = 0;       // rows per tile 128 / 256 (0: by form)
+    int wide_min_batch = 129;     // smallest batch for the 256 x 256-tile kernel
+    int scan_wg_per_cu = 0;       // scan workgroups per CU (0: one for a single query, occupancy otherwise)
+    int scan_nontemporal = -1;    // -1: streaming row loads on shards beyond the caches; 0 / 1
+    int timing_mfma = 0;          // MTR_TIMING_SWITCHES builds only: drop candidates / skip loads or MFMAs (wrong results)
+    int timing_wide = 0;          // MTR_TIMING_SWITCHES builds only
+    float timing_floor = 0.f;     // MTR_TIMING_SWITCHES builds only
+};
+Tuning& tuning();
+
 // ---- host-callable launchers (defined in the .hip files) -------------------
 
 // Row loader: finiteness check, optional L2 normalisation (float64 norm; norms

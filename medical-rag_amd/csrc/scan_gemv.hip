@@ -348,6 +348,7 @@ int plan_scan(int dtype, int64_t n, int d, int ld, int b, int k, int num_cus, Sc
     plan->lds = scan_lds_bytes(qb, plan->qstride, k);
     // Rows larger than the Infinity Cache gain nothing from being cached.
     plan->nontemporal = ((double)n * ld * esize > 192.0 * 1024 * 1024) ? 1 : 0;
+    if (tuning().scan_nontemporal >= 0) plan->nontemporal = tuning().scan_nontemporal != 0;
     int occ;
     if (dtype == 0)
         occ = plan->nontemporal ? occupancy_qb<float, true>(qb, plan->lds) : occupancy_qb<float, false>(qb, plan->lds);
@@ -362,7 +363,7 @@ int plan_scan(int dtype, int64_t n, int d, int ld, int b, int k, int num_cus, Sc
     // 0.457 against 0.464 ms with two).  Several queries per pass need the
     // occupancy to hide their longer dependent chains.
     long long cap = (long long)num_cus * (qb == 1 ? 1 : occ);
-    if (const char* e = getenv("MTR_SCAN_WG_PER_CU")) cap = atoi(e) > 0 ? (long long)num_cus * atoi(e) : cap;
+    if (tuning().scan_wg_per_cu > 0) cap = (long long)num_cus * tuning().scan_wg_per_cu;
     plan->grid = (int)(want < cap ? want : cap);
     if (plan->grid < 1) plan->grid = 1;
     return 0;

@@ -65,6 +65,14 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
 using f32x4v = __attribute__((ext_vector_type(4))) float;
 
+// Timing-experiment switches (results are then wrong by design) exist only in
+// builds with -DMTR_TIMING_SWITCHES; the default build folds them to zero.
+#ifdef MTR_TIMING_SWITCHES
+#define MTR_TIMING(a) (a).debug_no_candidates
+#else
+#define MTR_TIMING(a) 0
+#endif
+
 struct MfmaArgs {
     const char* rows;        // [n][ld] elements of T
     long long n;
@@ -255,7 +263,7 @@ __device__ __forceinline__ void append_above(f32x16& tile, float thr, int ql, lo
         if (pass) {
             const int np = __popc(pass);
             slot = atomicAdd(&cnt_lds[ql], np);
-            if (a.debug_no_candidates & 4) atomicAdd(a.debug_counters, (unsigned long long)np);
+            if (MTR_TIMING(a) & 4) atomicAdd(a.debug_counters, (unsigned long long)np);
         }
         // Registers any lane wants to store, as a wave-uniform mask: the
         // sixteen tests below are then scalar branches.  (Letting every
@@ -270,7 +278,7 @@ __device__ __forceinline__ void append_above(f32x16& tile, float thr, int ql, lo
         for (int r = 0; r < 16; ++r) {
             if (any_r & (1u << r)) {
                 if (pass & (1u << r)) {
-                    if (a.debug_no_candidates & 2) slot &= CAP - 1;
+                    if (MTR_TIMING(a) & 2) slot &= CAP - 1;
                     if (slot < CAP) dst[slot] = pack_key(tile[r], (int)(row0 + (r & 3) + 8 * (r >> 2)));
                     ++slot;
                 }
@@ -298,8 +306,8 @@ __device__ __forceinline__ void reselect_where_full(int q0, int nq, int tile_row
     constexpr int E = CAP / 64;
     const int c = cnt_lds[q0 + (lane % nq)];
     unsigned long long need = __ballot(lane < nq && c + tile_rows > CAP);  // k + slack + tile_rows <= CAP by plan
-    if (a.debug_no_candidates & 2) need = 0;
-    if ((a.debug_no_candidates & 4) && lane == 0 && need) atomicAdd(a.debug_counters + 1, (unsigned long long)__popcll(need));
+    if (MTR_TIMING(a) & 2) need = 0;
+    if ((MTR_TIMING(a) & 4) && lane == 0 && need) atomicAdd(a.debug_counters + 1, (unsigned long long)__popcll(need));
     while (need) {
         const int j = __ffsll((long long)need) - 1;
         need &= need - 1;
@@ -410,7 +418,7 @@ __global__ __launch_bounds__(TM == 256 ? 512 : 256, TM == 256 ? 1 : 2) void scor
     for (int i = tid; i < TN; i += kThreads) {
         const int qg = qt * TN + i;
         // padding queries collect nothing; the timing-only debug mode collects nothing at all
-        floor_lds[i] = (qg < a.b && !(a.debug_no_candidates & 1)) ? ((a.debug_no_candidates & 16) ? a.debug_floor : -__builtin_huge_valf())
+        floor_lds[i] = (qg < a.b && !(MTR_TIMING(a) & 1)) ? ((MTR_TIMING(a) & 16) ? a.debug_floor : -__builtin_huge_valf())
                                                                  : __builtin_huge_valf();
         cnt_lds[i] = 0;
         // floors known before the launch (from a sample of the rows) or already published by faster ranges
@@ -463,7 +471,7 @@ __global__ __launch_bounds__(TM == 256 ? 512 : 256, TM == 256 ? 1 : 2) void scor
             if (ks == 0 && tid < TN)
                 pending_floor = __hip_atomic_load(shared_floor + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const char* st = stage0 + cur * kStageBytes;
-            if (!(a.debug_no_candidates & 32)) mfma_step<MT, NT>(T{}, st, st + TM * kStepBytes, row_off, q_off, lane, acc);
+            if (!(MTR_TIMING(a) & 32)) mfma_step<MT, NT>(T{}, st, st + TM * kStepBytes, row_off, q_off, lane, acc);
             cur = cur == NS - 1 ? 0 : cur + 1;
             if (ks + 1 == ksteps) {
                 const long long row_base = ptile * TM + row_off + 4 * (lane >> 5);
@@ -503,13 +511,13 @@ __global__ __launch_bounds__(TM == 256 ? 512 : 256, TM == 256 ? 1 : 2) void scor
         const int cur = (int)(s & 1);
         if (ks == 0 && tid < TN)
             pending_floor = __hip_atomic_load(shared_floor + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (s + 1 < total_steps && !(a.debug_no_candidates & 64)) {
+        if (s + 1 < total_steps && !(MTR_TIMING(a) & 64)) {
             const int nks = ks + 1 == ksteps ? 0 : ks + 1;
             const long long ntile = ks + 1 == ksteps ? ptile_next : ptile;
             stage_tile<ROW_AUX, TM, WAVES>(a.rows, ntile * TM, a.n - 1, row_bytes, nks * kStepBytes, stage0 + (cur ^ 1) * kStageBytes, wave, lane);
             stage_tile<0, TNQ, WAVES>(qbase, 0, TN - 1, row_bytes, nks * kStepBytes, stage0 + (cur ^ 1) * kStageBytes + TM * kStepBytes, wave, lane);
         }
-        if (!(a.debug_no_candidates & 32))
+        if (!(MTR_TIMING(a) & 32))
         mfma_step<MT, NT>(T{}, stage0 + cur * kStageBytes, stage0 + cur * kStageBytes + TM * kStepBytes, row_off, q_off,
                           lane, acc);
 
@@ -593,10 +601,8 @@ int plan_mfma(int dtype, int64_t n, int ld, int b, int k, int num_cus, int sampl
         const long long row_tiles = (n + kTileRows - 1) / kTileRows;
         while (plan->tnq > 32 && row_tiles * ((b + plan->tnq - 1) / plan->tnq) < num_cus) plan->tnq /= 2;
     }
-    if (const char* e = getenv("MTR_MFMA_TNQ")) {
-        const int t = atoi(e);
-        if (t == 32 || t == 64 || t == 128) plan->tnq = t;
-    }
+    const Tuning& tn = tuning();
+    if (tn.mfma_tnq == 32 || tn.mfma_tnq == 64 || tn.mfma_tnq == 128) plan->tnq = tn.mfma_tnq;
     plan->n_qtiles = (b + plan->tnq - 1) / plan->tnq;
     // Row loads carry the streaming (nt) policy when every row byte is fetched
     // once per launch -- a single query tile -- and the rows exceed the Infinity
@@ -606,7 +612,7 @@ int plan_mfma(int dtype, int64_t n, int ld, int b, int k, int num_cus, int sampl
     // lines would leave first.  (A sampling launch reads a small part of the
     // rows, which the full launch reads again: default policy, two buffers.)
     plan->stream_rows = (!sampling && plan->n_qtiles == 1 && (double)n * ld * esize > 192.0 * 1024 * 1024) ? 1 : 0;
-    if (const char* e = getenv("MTR_MFMA_STREAM_ROWS")) plan->stream_rows = !sampling && atoi(e) != 0;
+    if (tn.mfma_stream_rows >= 0) plan->stream_rows = !sampling && tn.mfma_stream_rows != 0;
     // ... and, for the 32- and 64-query tiles of bf16 shards, the three-buffer
     // ring (12.5M x 768 bf16, 64 queries: 3.16 -> 3.07 ms; 1M x 1024: 0.394 ->
     // 0.375 ms; fp32 shards are bound by the fp32 matrix rate there and lose 1-2 %
@@ -614,18 +620,15 @@ int plan_mfma(int dtype, int64_t n, int ld, int b, int k, int num_cus, int sampl
     // The 128-query tile has the ring only in its 256-row form (below).
     const bool tall_shape = plan->tnq >= 64 && dtype == 2 && k <= 128;
     plan->stages = (plan->stream_rows && dtype == 2 && (plan->tnq <= 64 || tall_shape)) ? 3 : 2;
-    if (const char* e = getenv("MTR_MFMA_STAGES")) plan->stages = (!sampling && atoi(e) == 3 && (plan->tnq <= 64 || tall_shape)) ? 3 : 2;
+    if (tn.mfma_stages) plan->stages = (!sampling && tn.mfma_stages == 3 && (plan->tnq <= 64 || tall_shape)) ? 3 : 2;
     // ... with 256-row tiles (eight waves) for the 64- and 128-query tiles (bf16, k <= 128).
     int tm = kTileRows;
     const bool tall_ok = plan->stages == 3 && tall_shape;
     if (tall_ok) tm = 256;
-    if (const char* e = getenv("MTR_MFMA_TILE_ROWS")) tm = (atoi(e) == 256 && tall_ok) ? 256 : kTileRows;
+    if (tn.mfma_tile_rows) tm = (tn.mfma_tile_rows == 256 && tall_ok) ? 256 : kTileRows;
     if (tm == kTileRows && plan->tnq == 128) plan->stages = 2;
     plan->cap = (k <= 32 && tm == 128) ? 256 : 512;
-    if (const char* e = getenv("MTR_MFMA_CAP")) {
-        const int c = atoi(e);
-        if ((c == 256 || c == 512) && k + tm <= c) plan->cap = c;
-    }
+    if ((tn.mfma_cap == 256 || tn.mfma_cap == 512) && k + tm <= tn.mfma_cap) plan->cap = tn.mfma_cap;
     plan->slack = (plan->cap - tm - k) / 4;
     if (plan->slack > 64) plan->slack = 64;
     plan->tm = tm;
@@ -637,7 +640,7 @@ int plan_mfma(int dtype, int64_t n, int ld, int b, int k, int num_cus, int sampl
     // the 64- and 128-query tiles.  Two ring workgroups fit a CU's LDS, one of
     // the eight-wave 256-row form.
     long long per_cu = tm == 256 ? 1 : plan->stages == 3 ? 2 : plan->tnq == 32 ? 3 : 2;
-    if (const char* e = getenv("MTR_MFMA_PER_CU")) per_cu = (atoi(e) > 0 && tm != 256) ? atoi(e) : per_cu;
+    if (tn.mfma_per_cu > 0 && tm != 256) per_cu = tn.mfma_per_cu;
     // rounded down: a grid a few workgroups above per_cu * CUs runs those in a second round
     long long ranges = per_cu * num_cus / plan->n_qtiles;
     if (ranges > n_tiles) ranges = n_tiles;
@@ -667,9 +670,12 @@ hipError_t launch_score_mfma(const void* rows, int dtype, int64_t n, int ld, con
     a.tile_max = pass.tile_max;
     a.k = k;
     a.slack = plan.slack;
-    a.debug_no_candidates = getenv("MTR_MFMA_DEBUG") ? atoi(getenv("MTR_MFMA_DEBUG")) : 0;
+    a.debug_no_candidates = 0;
     a.debug_counters = nullptr;
-    a.debug_floor = getenv("MTR_MFMA_DEBUG_FLOOR") ? (float)atof(getenv("MTR_MFMA_DEBUG_FLOOR")) : 0.f;
+    a.debug_floor = 0.f;
+#ifdef MTR_TIMING_SWITCHES
+    a.debug_no_candidates = tuning().timing_mfma;
+    a.debug_floor = tuning().timing_floor;
     if (a.debug_no_candidates & 4) {
         static unsigned long long* counters = nullptr;
         if (!counters && hipMalloc(reinterpret_cast<void**>(&counters), 16) != hipSuccess) return hipErrorOutOfMemory;
@@ -679,6 +685,7 @@ hipError_t launch_score_mfma(const void* rows, int dtype, int64_t n, int ld, con
         (void)hipMemset(counters, 0, 16);
         a.debug_counters = counters;
     }
+#endif
     a.cand_buf = static_cast<unsigned long long*>(cand_buf);
     a.shared_floor = shared_floor;
     a.out_s = out_s;

@@ -82,6 +82,14 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
+// Timing-experiment switches (results are then wrong by design) exist only in
+// builds with -DMTR_TIMING_SWITCHES; the default build folds them to zero.
+#ifdef MTR_TIMING_SWITCHES
+#define MTR_TIMING(a) (a).debug
+#else
+#define MTR_TIMING(a) 0
+#endif
+
 struct WideArgs {
     const char* rows;         // [n][ld] bf16
     long long n;
@@ -225,7 +233,7 @@ __global__ __launch_bounds__(kWideThreads, 2) void score_filter_wide_kernel(Wide
     const int qt = wgid / a.n_lists, list = wgid % a.n_lists;
     long long my_tiles = a.n_tiles > list ? (a.n_tiles - list + a.n_lists - 1) / a.n_lists : 0;
     long long tile_step = a.n_lists, tile_first = list;
-    if (a.debug & 2) {  // contiguous ranges
+    if (MTR_TIMING(a) & 2) {  // contiguous ranges
         const long long tpr = (a.n_tiles + a.n_lists - 1) / a.n_lists;
         tile_first = list * tpr;
         tile_step = 1;
@@ -243,7 +251,7 @@ __global__ __launch_bounds__(kWideThreads, 2) void score_filter_wide_kernel(Wide
     for (int nn = 0; nn < 4; ++nn) {
         const int q = qt * kWideTile + wn * 64 + nn * 16 + (lane & 15);
         thr[nn] = __builtin_huge_valf();  // padding queries collect nothing
-        if (!MAX_ONLY && q < a.b && !(a.debug & 1)) {
+        if (!MAX_ONLY && q < a.b && !(MTR_TIMING(a) & 1)) {
             const unsigned int f = a.floor[q];
             thr[nn] = unorder_f32(f | (f == 0 ? 0x007fffffu : 0u));  // no floor: -inf
         }
@@ -357,7 +365,7 @@ __global__ __launch_bounds__(kWideThreads, 2) void score_filter_wide_kernel(Wide
                 }
             } else {
                 const int row_base = (int)(ptile * kWideTile) + wm * 128 + 4 * (lane >> 4);
-                if (!(a.debug & 4))
+                if (!(MTR_TIMING(a) & 4))
 #pragma unroll
                 for (int nn = 0; nn < 4; ++nn) {
                     const int ql = wn * 64 + nn * 16 + (lane & 15);
@@ -456,7 +464,10 @@ hipError_t launch_score_wide(const void* rows, int64_t n, int ld, const void* qu
     a.keys = keys;
     a.counts = counts;
     a.cap = plan.cap;
-    a.debug = getenv("MTR_WIDE_DEBUG") ? atoi(getenv("MTR_WIDE_DEBUG")) : 0;
+    a.debug = 0;
+#ifdef MTR_TIMING_SWITCHES
+    a.debug = tuning().timing_wide;
+#endif
     // the last tile of the launch must exist in the matrix
     if ((plan.n_tiles - 1) * a.tile_stride * kWideTile >= n) return hipErrorInvalidValue;
     auto launch = [&](auto kernel) -> hipError_t {

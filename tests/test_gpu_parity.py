@@ -240,15 +240,7 @@ def test_integer_data_is_exact_with_many_ties(native, store):
     corpus = rng.integers(-2, 3, size=(n, d)).astype(np.float32)
     queries = rng.integers(-2, 3, size=(b, d)).astype(np.float32)
     shard = native.DeviceShard.from_host(corpus, store_dtype=store, normalize=False)
-    old = os.environ.get("MTR_MFMA_SAMPLE_STRIDE")
-    try:
-        os.environ["MTR_MFMA_SAMPLE_STRIDE"] = "12"
-        idx, score = shard.search(queries, k=k, metric="ip")
-    finally:
-        if old is None:
-            os.environ.pop("MTR_MFMA_SAMPLE_STRIDE", None)
-        else:
-            os.environ["MTR_MFMA_SAMPLE_STRIDE"] = old
+    idx, score = _search_with_env(shard, queries, k, metric="ip", MTR_MFMA_SAMPLE_STRIDE=12)
     want_i, want_s = orc.search(queries, corpus, k, metric="ip")
     assert (idx == want_i).all() and (score == want_s.astype(np.float32)).all()
     shard.close()
@@ -441,37 +433,20 @@ def test_sampled_two_launch_search_equals_single_launch(native, store, stride):
         corpus[row] = corpus[5]
     queries[0] = corpus[5]
     shard = native.DeviceShard.from_host(corpus, store_dtype=store)
-    old = os.environ.get("MTR_MFMA_SAMPLE_STRIDE")
-    try:
-        os.environ["MTR_MFMA_SAMPLE_STRIDE"] = "0"
-        one_i, one_s = shard.search(queries, k=k)
-        os.environ["MTR_MFMA_SAMPLE_STRIDE"] = str(stride)
-        two_i, two_s = shard.search(queries, k=k)
-    finally:
-        if old is None:
-            os.environ.pop("MTR_MFMA_SAMPLE_STRIDE", None)
-        else:
-            os.environ["MTR_MFMA_SAMPLE_STRIDE"] = old
+    one_i, one_s = _search_with_env(shard, queries, k, MTR_MFMA_SAMPLE_STRIDE=0)
+    two_i, two_s = _search_with_env(shard, queries, k, MTR_MFMA_SAMPLE_STRIDE=stride)
     assert (one_i == two_i).all() and (one_s == two_s).all()
     assert one_i[0, :4].tolist() == [5, 128 * stride + 3, 128 * (stride + 1) + 9, n - 2]
     check_topk(two_i, two_s, orc.scores(queries, corpus), k, 1e-6 if store == "fp32" else 2.0 ** -8)
     shard.close()
 
 
-def _search_with_env(shard, queries, k, metric="cosine", **env):
-    """One search with the given environment switches set (the library reads them on every search)."""
-    import os
-    old = {name: os.environ.get(name) for name in env}
-    try:
-        for name, value in env.items():
-            os.environ[name] = str(value)
+def _search_with_env(shard, queries, k, metric="cosine", **switches):
+    """One search with the given launch-shape switches set (MTR_MFMA_STAGES=3 sets
+    the library's process-wide switch "mfma_stages"; restored afterwards)."""
+    from medical_rag_amd import _native
+    with _native.options(**{name[4:].lower(): int(value) for name, value in switches.items()}):
         return shard.search(queries, k=k, metric=metric)
-    finally:
-        for name, value in old.items():
-            if value is None:
-                os.environ.pop(name, None)
-            else:
-                os.environ[name] = value
 
 
 @pytest.mark.parametrize("store,d", [("bf16", 256), ("bf16", 128), ("fp32", 192), ("fp32", 64)])
