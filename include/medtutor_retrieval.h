@@ -97,6 +97,26 @@ int mtr_index_search_device(mtr_index_t* index, const void* dev_queries, int32_t
                             int32_t b, int32_t k, int32_t metric,
                             int64_t* dev_out_idx, float* dev_out_score, void* stream);
 
+/* mtr_index_search_device for callers that cannot allocate device memory: code
+ * under HIP stream capture, tight serving loops, harnesses that forbid
+ * hipMalloc.  No counterpart in the reference.  Same arguments, same kernels and
+ * bit-identical results, but every scratch buffer (query tiles, candidate lists,
+ * floors) comes from a file-scope device array of MTR_NOALLOC_SCRATCH_BYTES that
+ * each GPU holds from library load to process end, and the call makes no
+ * hipMalloc / hipFree or other allocating call (no profiling events either).
+ * Limits: the search's scratch must fit the array -- every single-query search
+ * and every batch with b <= 64 and k <= 128 does; larger shapes are accepted
+ * when their launch plan fits and rejected with MTR_ERR_INVALID (the message
+ * names the bytes needed) otherwise.  All calls on one GPU, from any handle,
+ * share that GPU's array: calls that overlap on one GPU (different streams or
+ * threads without ordering between them) race; callers keep to one stream per
+ * GPU or order the calls themselves.  The handle's other entry points keep their
+ * own buffers and may be mixed in freely. */
+#define MTR_NOALLOC_SCRATCH_BYTES (192u << 20)
+int mtr_index_search_device_noalloc(mtr_index_t* index, const void* dev_queries, int32_t q_dtype,
+                                    int32_t b, int32_t k, int32_t metric,
+                                    int64_t* dev_out_idx, float* dev_out_score, void* stream);
+
 /* Whether the queries of the last mtr_index_search_device call on the handle
  * held a NaN or infinity (*nonfinite = 1; its results are then meaningless, and
  * the reference's scorer raises ValueError: pipeline/utils/local_rag.py:77).

@@ -32,6 +32,7 @@ SIGNATURES = {
     "mtr_index_create": (_i32, [_vp, _i64, _i32, _i32, _i32, _i32, _i32, _i64, _pp]),
     "mtr_index_search": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "mtr_index_search_device": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "mtr_index_search_device_noalloc": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "mtr_index_nonfinite": (_i32, [_vp, C.POINTER(_i32)]),
     "mtr_merge_topk_device": (_i32, [_vp, _vp, _i32, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
     "mtr_pool_normalize": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _vp]),
@@ -256,6 +257,26 @@ class DeviceShard:
         check(lib().mtr_index_search_device(self._h, C.c_void_p(queries.data_ptr()), torch_dtype_code(queries), b,
                                             int(k), METRICS[metric], C.c_void_p(idx.data_ptr()),
                                             C.c_void_p(score.data_ptr()), C.c_void_p(stream)))
+        return idx, score
+
+    def search_device_noalloc(self, queries, out, k=10, metric="cosine", stream=None):
+        """search_device through the allocation-free entry point: the caller
+        brings the (B, k) int64 / float32 output tensors, the library takes its
+        scratch from a static device array and allocates nothing."""
+        import torch
+        idx, score = out
+        b = queries.shape[0]
+        if (not queries.is_cuda or not queries.is_contiguous() or queries.dim() != 2 or queries.shape[1] != self.d
+                or queries.device.index != self.device):
+            raise ValueError("search_device_noalloc wants a contiguous (B, d) tensor on the shard's GPU")
+        for t, dt in ((idx, torch.int64), (score, torch.float32)):
+            if t.device != queries.device or t.dtype != dt or t.numel() != b * k or not t.is_contiguous():
+                raise ValueError("out must be contiguous (B, k) int64 / float32 tensors on the shard's GPU")
+        if stream is None:
+            stream = torch.cuda.current_stream(queries.device).cuda_stream
+        check(lib().mtr_index_search_device_noalloc(self._h, C.c_void_p(queries.data_ptr()), torch_dtype_code(queries),
+                                                    b, int(k), METRICS[metric], C.c_void_p(idx.data_ptr()),
+                                                    C.c_void_p(score.data_ptr()), C.c_void_p(stream)))
         return idx, score
 
     def nonfinite(self) -> bool:

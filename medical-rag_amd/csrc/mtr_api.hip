@@ -82,6 +82,38 @@ struct DeviceGuard {
 
 }  // namespace
 
+// Scratch memory of the allocation-free entry point
+// (mtr_index_search_device_noalloc): a file-scope device array instead of
+// buffers from hipMalloc.  Every GPU the library runs on holds its own copy, at
+// its own address, until the process ends.  The name is a host-side stand-in
+// for the symbol, not a device address: host code only ever uses the per-device
+// address that hipGetSymbolAddress returned (static_scratch_for).  That host
+// reference is also what makes the compiler give the device-side symbol
+// external visibility, which the runtime's lookup needs (marking the array
+// `used` instead keeps it local, and the lookup then fails).
+constexpr size_t kStaticScratchBytes = (size_t)MTR_NOALLOC_SCRATCH_BYTES;
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu;
+unsigned char* g_scratch_ptr[kMaxDevices] = {};
+
+// The calling thread's current device must be `device`.
+int static_scratch_for(int device, unsigned char** out) {
+    if (device < 0 || device >= kMaxDevices) return fail(MTR_ERR_INVALID, "device %d out of range", device);
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[device]) {
+        void* ptr = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        if (!ptr) return fail(MTR_ERR_HIP, "hipGetSymbolAddress returned NULL for the scratch array on device %d", device);
+        g_scratch_ptr[device] = static_cast<unsigned char*>(ptr);
+    }
+    *out = g_scratch_ptr[device];
+    return MTR_OK;
+}
+}  // namespace
+
 // The device buffers a search needs beyond its inputs and outputs.
 enum ScratchSlot {
     kQF32,        // padded fp32 queries of one scan pass
@@ -124,6 +156,7 @@ struct mtr_index {
     hipEvent_t last_use = nullptr;
     hipStream_t last_stream = nullptr;
     bool used = false;
+    unsigned char* static_scratch = nullptr;  // this device's copy of the file-scope scratch array
     // profiling
     bool profiling = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -155,6 +188,31 @@ struct Scratch {
     bool keeps_query_tiles() const { return true; }
     bool may_profile() const { return true; }
     bool allows_wide() const { return true; }
+};
+
+// ... or, for the allocation-free entry point, from the device's static array:
+// a bump allocation per call, nothing kept from one call to the next.
+struct StaticScratch {
+    mtr_index* ix = nullptr;
+    void* p[kScratchSlots] = {};
+    size_t used = 0;
+    int need(ScratchSlot slot, size_t bytes) {
+        used = (used + 255) & ~(size_t)255;
+        if (used + bytes <= kStaticScratchBytes) p[slot] = ix->static_scratch + used;
+        used += bytes;
+        return MTR_OK;
+    }
+    int ready() const {
+        if (used > kStaticScratchBytes)
+            return fail(MTR_ERR_INVALID,
+                        "this search needs %zu bytes of scratch, the allocation-free entry point has %zu: use a smaller "
+                        "batch or k, or mtr_index_search_device",
+                        used, kStaticScratchBytes);
+        return MTR_OK;
+    }
+    bool keeps_query_tiles() const { return false; }
+    bool may_profile() const { return false; }   // creating events allocates
+    bool allows_wide() const { return false; }   // its key lists run to gigabytes
 };
 
 // Makes `stream` wait for whatever was last enqueued on the handle from another
@@ -455,6 +513,14 @@ int mtr_index_alloc(int64_t n, int32_t d, int32_t store_dtype, int32_t normalize
         mtr_index_destroy(ix);
         return fail(MTR_ERR_HIP, "shard set-up: %s", hipGetErrorString(e));
     }
+    // the shard's GPU is current (guard): its address of the static scratch array
+    int rc = static_scratch_for(device_id, &ix->static_scratch);
+    if (rc != MTR_OK) {
+        std::string keep = g_err;
+        mtr_index_destroy(ix);
+        g_err = keep;
+        return rc;
+    }
     *out = ix;
     return MTR_OK;
 }
@@ -601,6 +667,21 @@ int mtr_index_search_device(mtr_index_t* ix, const void* dev_queries, int32_t q_
     const int rc2 = end_use(ix, s);
     if (rc != MTR_OK) g_err = keep;
     return rc != MTR_OK ? rc : rc2;
+}
+
+int mtr_index_search_device_noalloc(mtr_index_t* ix, const void* dev_queries, int32_t q_dtype, int32_t b, int32_t k,
+                                    int32_t metric, int64_t* dev_out_idx, float* dev_out_score, void* stream) {
+    int rc = check_search_args(ix, dev_queries, dev_out_idx, dev_out_score, q_dtype, b, k, metric);
+    if (rc != MTR_OK) return rc;
+    std::lock_guard<std::mutex> lock(ix->mu);
+    DeviceGuard guard(ix->device);
+    if (!ix->static_scratch) return fail(MTR_ERR_HIP, "the static scratch array was not resolved on device %d", ix->device);
+    // No events and no cross-stream ordering here: this entry point may run under
+    // stream capture, and its callers keep to one stream per GPU.
+    StaticScratch sc;
+    sc.ix = ix;
+    return enqueue_search(ix, sc, dev_queries, q_dtype, b, k, metric, reinterpret_cast<long long*>(dev_out_idx),
+                          dev_out_score, static_cast<hipStream_t>(stream));
 }
 
 int mtr_index_nonfinite(mtr_index_t* ix, int32_t* nonfinite) {
