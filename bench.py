@@ -5,7 +5,8 @@
 
 One "step" is one search call: B queries scored against the whole corpus with
 exact top-k, corpus and queries already resident in HBM.  With N > 1 (launched
-by torch.distributed.run, one rank per GPU) the corpus is row-sharded over the
+by torch.distributed.run, or by this script itself from a bare shell, one rank
+per GPU) the corpus is row-sharded over the
 ranks (total size fixed: strong scaling) and each step ends with the RCCL
 all-gather of the per-rank candidates and the k-way merge.
 
@@ -82,7 +83,7 @@ def pmc_traffic(workload, default_shape):
     the profiled shape."""
     import glob
     if not default_shape:
-        return None
+        return None, None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")), reverse=True):
         try:
             with open(path) as f:
@@ -90,8 +91,8 @@ def pmc_traffic(workload, default_shape):
         except (OSError, ValueError):
             continue
         if rec:
-            return rec["traffic_bytes_per_launch"]
-    return None
+            return rec["traffic_bytes_per_launch"], os.path.relpath(path, ROOT)
+    return None, None
 
 
 def cpu_baseline(dim, k, full_rows, budget_s=12.0):
@@ -128,6 +129,24 @@ def cpu_baseline(dim, k, full_rows, budget_s=12.0):
         if el2 > 3.0 or m_calls >= 50:
             break
     per_call32 = el2 / m_calls
+    # ... and the float64 restatement on ONE core (BLAS threads limited to 1)
+    one_core = None
+    try:
+        from threadpoolctl import threadpool_limits
+        small = corpus[: sample_rows // 4]
+        with threadpool_limits(limits=1):
+            orc.search(q, small, k)
+            c_calls, t2 = 0, time.perf_counter()
+            while True:
+                orc.search(q, small, k)
+                c_calls += 1
+                el3 = time.perf_counter() - t2
+                if el3 > 4.0 or c_calls >= 20:
+                    break
+        one_core = {"value": 1.0 / (el3 / c_calls * full_rows / len(small)), "unit": "queries/s", "cores": 1,
+                    "sample": f"{c_calls} calls over {len(small)}x{dim} rows, scaled linearly"}
+    except ImportError:
+        pass
     return {
         "value": 1.0 / (per_call * full_rows / sample_rows),
         "unit": "queries/s",
@@ -135,9 +154,29 @@ def cpu_baseline(dim, k, full_rows, budget_s=12.0):
         "kind": "port",
         "sample": f"numpy float64 oracle, {n_calls} single-query calls over a {sample_rows}x{dim} row sample "
                   f"({per_call * 1e3:.1f} ms/call), scaled linearly to {full_rows} rows",
+        "one_core": one_core,
         "prenormalised_fp32_sgemv": {"value": 1.0 / (per_call32 * full_rows / sample_rows), "unit": "queries/s",
                                      "ms_per_call_on_sample": per_call32 * 1e3},
     }
+
+
+def launch_ranks(n_gpus):
+    """`python bench.py --gpus N` from a bare shell: this process has touched no
+    GPU yet; it starts one child per GPU with the torch.distributed environment
+    set (what torch.distributed.run would do), lets rank 0 print the JSON line
+    and returns the worst exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    children = []
+    for rank in range(n_gpus):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n_gpus),
+                   LOCAL_WORLD_SIZE=str(n_gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        children.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    codes = [child.wait() for child in children]
+    return max((abs(c) for c in codes), default=0)
 
 
 def main():
@@ -152,11 +191,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-exchange", action="store_true",
                     help="initialise the process group and run the all-gather + merge even with one rank")
+    ap.add_argument("--torch-exchange", action="store_true",
+                    help="all-gather through torch.distributed instead of the library's RCCL communicator")
     ap.add_argument("--pipeline-depth", type=int, default=-1,
                     help="multi-GPU runs: searches whose exchange may still be in flight when the next scan starts "
                          "(0: every search waits for its own exchange on the main stream; default: 2 from four "
                          "ranks, where the all-gather takes long enough to be worth hiding, else 0)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))   # nothing in this process has touched a GPU
 
     import torch
     import torch.distributed as dist
@@ -167,12 +211,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"rank {rank} wants GPU {local_rank}, but only {torch.cuda.device_count()} are visible")
     torch.cuda.set_device(local_rank)
+    comm = None
     if world > 1 or args.force_exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
+        # torch.distributed carries the RCCL unique id, the barriers and the max over ranks of the
+        # elapsed time; the searches' all-gather runs on the library's own communicator.
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        if not args.torch_exchange:
+            comm = native.Comm.from_process_group(local_rank)
 
     w = dict(WORKLOADS[args.workload])
     if args.rows:
@@ -192,11 +243,13 @@ def main():
         for j in range(k):
             needles.append((qi, j, (qi * 7919 + (j * 2 + 1) * (rows // (2 * k)) + 13) % rows))
     lo, hi = shard_bounds(rows, world, rank)
+    if hi <= lo:
+        raise SystemExit(f"rank {rank} would hold no rows ({rows} rows over {world} ranks)")
     t_build = time.perf_counter()
     shard = build_shard(native, torch, lo, hi, dim, store, local_rank, needles, queries, k)
     torch.cuda.synchronize()
     t_build = time.perf_counter() - t_build
-    index = ShardedIndex(shard, always_exchange=args.force_exchange)
+    index = ShardedIndex(shard, always_exchange=args.force_exchange, comm=comm)
 
     # Steps are independent searches.  With several ranks the all-gather and the
     # final merge of a search run on a side stream while the next search's scan
@@ -271,7 +324,7 @@ def main():
         achieved = local_bytes / (scan_avg_ms * 1e-3) / 1e9
         passes = n_launch / args.steps
         default_shape = world == 1 and not (args.rows or args.batch or args.k)
-        traffic = pmc_traffic(args.workload, default_shape)
+        traffic, traffic_file = pmc_traffic(args.workload, default_shape)
         # The library hands batches of >= 2 (bf16) / 3 (fp32) queries to the matrix-core
         # kernel when rows are a multiple of 128 bytes (>= 256) and k <= 256.
         min_b = int(os.environ.get("MTR_MFMA_MIN_BATCH", "0") or 0) or (2 if store == "bf16" else 3)
@@ -295,6 +348,9 @@ def main():
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "kernel": kernel, "kernel_avg_ms": scan_avg_ms,
                     "launches_per_step": passes, "algorithmic_bytes_per_launch": local_bytes}
+        if traffic is not None:
+            roof["traffic_source"] = (f"{traffic_file}: separate rocprofv3 --pmc passes over this command, committed; "
+                                      "not collected during this run")
         for r in (roof,):  # spread of the per-launch HIP-event times behind kernel_avg_ms
             if samples:
                 r["kernel_ms_p50"] = samples[len(samples) // 2]
@@ -315,6 +371,8 @@ def main():
             "config": {"workload": w["name"], "rows": rows, "dim": dim, "batch": batch, "k": k,
                        "rows_per_gpu": hi - lo,
                        "parallelism": f"row-shard x{world}" + (" + RCCL all-gather + k-way merge" if world > 1 else ""),
+                       "exchange": ("library RCCL communicator (mtr_sharded_search_device)" if comm is not None
+                                    else "torch.distributed" if exchanging else None),
                        "exchange_pipeline_depth": depth},
             "roofline": roof,
             "needles_found": bool(needle_ok),
@@ -324,6 +382,8 @@ def main():
             res["cpu_baseline"] = cpu_baseline(dim, k, rows)
         print(json.dumps(res), flush=True)
     shard.close()
+    if comm is not None:
+        comm.close()
     if dist.is_initialized():
         dist.destroy_process_group()
     if not needle_ok:

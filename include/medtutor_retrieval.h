@@ -35,6 +35,7 @@ extern "C" {
 #endif
 
 typedef struct mtr_index mtr_index_t;
+typedef struct mtr_comm mtr_comm_t;
 
 enum {
     MTR_OK = 0,
@@ -137,6 +138,38 @@ int mtr_merge_topk_device(const int64_t* dev_idx, const float* dev_score, int32_
                           int32_t b, int32_t k_in, int32_t k_out,
                           int64_t* dev_out_idx, float* dev_out_score,
                           int32_t device_id, void* stream);
+
+/* ---- row-sharded search: one process per GPU, RCCL over xGMI ---------------
+ * The reference is single-shard (pipeline/utils/local_rag.py:78 is its whole
+ * "merge"); these entry points are what lets any host search a corpus that
+ * spans the GPUs of a node.  Each process holds the contiguous row block of its
+ * rank (row_offset = first global row) and a communicator; a search is
+ * local top-k -> ONE all-gather of b*k*12 bytes per rank -> k-way merge, and
+ * every rank ends with the same global result.  RCCL is loaded on first use. */
+#define MTR_COMM_ID_BYTES 128
+/* Rank 0 makes the id (MTR_COMM_ID_BYTES bytes) and ships it to the other ranks
+ * by any means (a file, a socket, torch.distributed's store). */
+int mtr_comm_unique_id(void* out_id);
+/* Collective: every rank calls it with the same id; blocks until all have. */
+int mtr_comm_create(const void* unique_id, int32_t rank, int32_t world, int32_t device_id,
+                    mtr_comm_t** out);
+int mtr_comm_info(const mtr_comm_t* comm, int32_t* rank, int32_t* world, int32_t* device_id);
+void mtr_comm_destroy(mtr_comm_t* comm);
+/* Collective, enqueued on `stream` without synchronising: mtr_index_search_device
+ * on this rank's shard, the all-gather, the merge; dev_out_* (b*k each) receive
+ * the global top-k, identical on every rank.  index may be NULL for a rank that
+ * holds no rows (it contributes padding).  Every rank passes the same queries,
+ * b, k and metric.  Up to four calls may be in flight on different streams. */
+int mtr_sharded_search_device(mtr_index_t* index, mtr_comm_t* comm, const void* dev_queries,
+                              int32_t q_dtype, int32_t b, int32_t k, int32_t metric,
+                              int64_t* dev_out_idx, float* dev_out_score, void* stream);
+/* The exchange step alone, for callers that overlap it with the next search on
+ * another stream: this rank's local candidates (b x k_in; both NULL = none) are
+ * all-gathered and merged into the global best k_out per query. */
+int mtr_comm_exchange_merge_device(mtr_comm_t* comm, const int64_t* dev_local_idx,
+                                   const float* dev_local_score, int32_t b, int32_t k_in,
+                                   int32_t k_out, int64_t* dev_out_idx, float* dev_out_score,
+                                   void* stream);
 
 /* Encoder epilogue on GPU device_id: masked mean over the t tokens of each of
  * b sequences, then L2 normalisation (eps 1e-12), written as fp32 rows that

@@ -35,6 +35,12 @@ SIGNATURES = {
     "mtr_index_search_device_noalloc": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "mtr_index_nonfinite": (_i32, [_vp, C.POINTER(_i32)]),
     "mtr_merge_topk_device": (_i32, [_vp, _vp, _i32, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
+    "mtr_comm_unique_id": (_i32, [_vp]),
+    "mtr_comm_create": (_i32, [_vp, _i32, _i32, _i32, _pp]),
+    "mtr_comm_info": (_i32, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
+    "mtr_comm_destroy": (None, [_vp]),
+    "mtr_sharded_search_device": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "mtr_comm_exchange_merge_device": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "mtr_pool_normalize": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _vp]),
     "mtr_index_info": (_i32, [_vp, C.POINTER(_i64), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32),
                               C.POINTER(_i32), C.POINTER(_i64)]),
@@ -314,6 +320,84 @@ class DeviceShard:
     def close(self):
         if self._h is not None and self._h.value:
             lib().mtr_index_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+MTR_COMM_ID_BYTES = 128
+
+
+class Comm:
+    """One rank's end of the library's RCCL communicator (mtr_comm_t*)."""
+
+    def __init__(self, handle, rank, world, device):
+        self._h, self.rank, self.world, self.device = handle, rank, world, device
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(MTR_COMM_ID_BYTES)
+        check(lib().mtr_comm_unique_id(buf))
+        return buf.raw
+
+    @classmethod
+    def create(cls, unique_id: bytes, rank: int, world: int, device: int):
+        """Collective: every rank calls it with rank 0's unique_id()."""
+        if len(unique_id) != MTR_COMM_ID_BYTES:
+            raise ValueError("unique_id must be MTR_COMM_ID_BYTES bytes")
+        out = C.c_void_p()
+        check(lib().mtr_comm_create(C.c_char_p(unique_id), int(rank), int(world), int(device), C.byref(out)))
+        return cls(out, rank, world, device)
+
+    @classmethod
+    def from_process_group(cls, device: int, group=None):
+        """Builds the communicator over the ranks of a torch.distributed group,
+        which only carries rank 0's id to the others."""
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return cls.create(box[0], rank, world, device)
+
+    def sharded_search(self, shard, queries, out, k=10, metric="cosine", stream=None):
+        """Local top-k on `shard` (None: this rank holds no rows), all-gather and
+        merge on one stream; out = (idx (B, k) int64, score (B, k) float32)."""
+        import torch
+        idx, score = out
+        b = queries.shape[0]
+        if not queries.is_cuda or not queries.is_contiguous() or queries.device.index != self.device:
+            raise ValueError("sharded_search wants a contiguous (B, d) tensor on the communicator's GPU")
+        if stream is None:
+            stream = torch.cuda.current_stream(queries.device).cuda_stream
+        handle = shard._h if shard is not None else None
+        check(lib().mtr_sharded_search_device(handle, self._h, C.c_void_p(queries.data_ptr()),
+                                              torch_dtype_code(queries), b, int(k), METRICS[metric],
+                                              C.c_void_p(idx.data_ptr()), C.c_void_p(score.data_ptr()),
+                                              C.c_void_p(stream)))
+        return idx, score
+
+    def exchange_merge(self, local, out, k_out, stream=None):
+        """local = (idx (B, k_in) int64, score (B, k_in) float32) of this rank, or
+        None when it has no rows; out receives the global best k_out."""
+        import torch
+        idx, score = out
+        if stream is None:
+            stream = torch.cuda.current_stream(idx.device).cuda_stream
+        b, k_in = (local[0].shape if local is not None else (idx.shape[0], k_out))
+        li = C.c_void_p(local[0].data_ptr()) if local is not None else None
+        ls = C.c_void_p(local[1].data_ptr()) if local is not None else None
+        check(lib().mtr_comm_exchange_merge_device(self._h, li, ls, int(b), int(k_in), int(k_out),
+                                                   C.c_void_p(idx.data_ptr()), C.c_void_p(score.data_ptr()),
+                                                   C.c_void_p(stream)))
+        return idx, score
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            lib().mtr_comm_destroy(self._h)
         self._h = None
 
     def __del__(self):

@@ -33,6 +33,23 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+}  // namespace
+
+namespace mtr {
+// The same message slot for the library's other source files.
+int set_error(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+}  // namespace mtr
+
+namespace {
+
 #define HIP_TRY(expr)                                                                      \
     do {                                                                                   \
         hipError_t e_ = (expr);                                                            \

@@ -6,7 +6,10 @@ global order and a lower rank means lower rows).  A search is
     local top-k (HIP scan)  ->  ONE all-gather of the packed (id, score)
     candidates over RCCL/xGMI  ->  k-way merge (HIP) on every rank,
 so every rank ends with the same global result.  The exchange is B*k*12 bytes
-per rank; it is latency-, not bandwidth-bound.
+per rank; it is latency-, not bandwidth-bound.  With the library's own
+communicator (_native.Comm, mtr_comm_create) the three steps are one C call,
+mtr_sharded_search_device; torch.distributed then only carries the RCCL unique
+id to the ranks.
 
 The reference is single-process and single-shard
 (pipeline/utils/local_rag.py:71-78); this module is what lets the same search
@@ -14,18 +17,19 @@ cover corpora that exceed one GPU.
 """
 from __future__ import annotations
 
-import math
 
 
 def shard_bounds(n_rows: int, world_size: int, rank: int):
-    """Rows [lo, hi) owned by `rank` when n_rows are split into contiguous
-    blocks of ceil(n/world) rows (the last blocks may be short or empty)."""
+    """Rows [lo, hi) owned by `rank`: contiguous blocks of n // world rows, the
+    first n % world ranks one row longer, so no rank is empty unless there are
+    fewer rows than ranks."""
     if world_size < 1 or not (0 <= rank < world_size):
         raise ValueError("bad world_size/rank")
-    per = math.ceil(n_rows / world_size) if n_rows > 0 else 0
-    lo = min(n_rows, rank * per)
-    hi = min(n_rows, lo + per)
-    return lo, hi
+    if n_rows < 0:
+        raise ValueError("n_rows must not be negative")
+    per, extra = divmod(n_rows, world_size)
+    lo = rank * per + min(rank, extra)
+    return lo, lo + per + (1 if rank < extra else 0)
 
 
 class CandidateBlock:
@@ -86,20 +90,32 @@ class PendingSearch:
 
 
 class ShardedIndex:
-    """This rank's shard plus the process group it searches with."""
+    """This rank's shard plus what it exchanges candidates with.
 
-    def __init__(self, shard, group=None, always_exchange=False):
+    shard: a DeviceShard, or None when this rank holds no rows (fewer rows than
+    ranks): it then contributes a block of padding (id -1, score -inf).
+    comm: the library's own RCCL communicator (_native.Comm) -- local search,
+    all-gather and merge are then ONE C call on one stream.  Without it the
+    exchange goes through torch.distributed (`group`), which is what the CPU
+    tests run over gloo, and `merge` does the final selection
+    (default: the HIP merge kernel)."""
+
+    def __init__(self, shard, group=None, always_exchange=False, comm=None, merge=None):
         self.shard = shard
         self.group = group
+        self.comm = comm
         # always_exchange: run the all-gather + merge even on a single rank (a
         # rehearsal of the multi-GPU path on one GPU).
         self.always_exchange = always_exchange
+        self._merge = merge
         self._bufs = {}
         self._rings = {}
         self._side = None
 
     @property
     def world_size(self):
+        if self.comm is not None:
+            return self.comm.world
         import torch.distributed as dist
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
 
@@ -114,30 +130,50 @@ class ShardedIndex:
             self._bufs[key] = hit
         return hit
 
-    def search_device(self, queries, k: int = 10, metric: str = "cosine"):
-        """queries: (B, d) GPU tensor, identical on every rank.  Returns the
-        global (ids (B, k) int64, scores (B, k) float32) on every rank,
-        enqueued on torch's current stream.  The returned tensors are reused
-        by the next call with the same (B, k)."""
+    def _local_search(self, queries, k, metric, mine):
+        """This rank's candidates into its block of the exchange buffer."""
+        if self.shard is None:
+            mine.ids[0].fill_(-1)
+            mine.scores[0].fill_(float("-inf"))
+        else:
+            self.shard.search_device(queries, k=k, metric=metric, out=(mine.ids[0], mine.scores[0]))
+
+    def _merge_all(self, everyone, k, out):
+        if self._merge is not None:
+            ids, scores = self._merge(everyone.ids, everyone.scores, k)
+            out[0].copy_(ids)
+            out[1].copy_(scores)
+            return out
         from . import _native
+        return _native.merge_topk_device(everyone.ids, everyone.scores, k, out=out)
+
+    def search_device(self, queries, k: int = 10, metric: str = "cosine"):
+        """queries: (B, d) tensor on this rank's device, identical on every rank.
+        Returns the global (ids (B, k) int64, scores (B, k) float32) on every
+        rank, enqueued on torch's current stream.  The returned tensors are
+        reused by the next call with the same (B, k)."""
         if queries.dim() == 1:
             queries = queries[None, :]
         b = queries.shape[0]
         mine, everyone, out_i, out_s = self._buffers(b, k, queries.device)
         if self.world_size == 1 and not self.always_exchange:
+            if self.shard is None:
+                raise ValueError("a single rank cannot search without rows")
             return self.shard.search_device(queries, k=k, metric=metric, out=(out_i, out_s))
-        self.shard.search_device(queries, k=k, metric=metric, out=(mine.ids[0], mine.scores[0]))
+        if self.comm is not None:
+            return self.comm.sharded_search(self.shard, queries, (out_i, out_s), k=k, metric=metric)
+        self._local_search(queries, k, metric, mine)
         exchange(mine, everyone, self.group)
-        return _native.merge_topk_device(everyone.ids, everyone.scores, k, out=(out_i, out_s))
+        return self._merge_all(everyone, k, (out_i, out_s))
 
     def search_device_async(self, queries, k: int = 10, metric: str = "cosine", depth: int = 2):
         """Throughput form for streams of independent searches.  The local search is
         enqueued on torch's current stream; the all-gather and the final merge
         go to a side stream, so the next search's scan overlaps with this one's
         exchange.  Returns a PendingSearch.  `depth` sets of buffers are cycled:
-        at most `depth` searches of one shape may be pending."""
+        at most `depth` searches of one shape may be pending (and at most three
+        with the library's communicator, which cycles four exchange buffers)."""
         import torch
-        from . import _native
         if queries.dim() == 1:
             queries = queries[None, :]
         b = queries.shape[0]
@@ -145,6 +181,8 @@ class ShardedIndex:
         if self.world_size == 1 and not self.always_exchange:
             ids, scores = self.search_device(queries, k=k, metric=metric)
             return PendingSearch(ids, scores, None)
+        if self.comm is not None and depth > 3:
+            raise ValueError("at most three searches may be pending on the library's communicator")
         key = (b, k, str(device), depth)
         ring = self._rings.get(key)
         if ring is None:
@@ -162,12 +200,16 @@ class ShardedIndex:
         if slot["done"] is not None:
             main.wait_event(slot["done"])   # the slot's previous exchange has read `mine` and written the outputs
         mine, everyone = slot["mine"], slot["everyone"]
-        self.shard.search_device(queries, k=k, metric=metric, out=(mine.ids[0], mine.scores[0]))
+        self._local_search(queries, k, metric, mine)
         slot["local_done"].record(main)
         with torch.cuda.stream(self._side):
             self._side.wait_event(slot["local_done"])
-            exchange(mine, everyone, self.group)
-            _native.merge_topk_device(everyone.ids, everyone.scores, k, out=(slot["ids"], slot["scores"]))
+            if self.comm is not None:
+                local = (mine.ids[0], mine.scores[0]) if self.shard is not None else None
+                self.comm.exchange_merge(local, (slot["ids"], slot["scores"]), k)
+            else:
+                exchange(mine, everyone, self.group)
+                self._merge_all(everyone, k, (slot["ids"], slot["scores"]))
             done = torch.cuda.Event()
             done.record(self._side)
         slot["done"] = done

@@ -685,6 +685,45 @@ def test_async_sharded_search_matches_sync(native):
         dist.destroy_process_group()
 
 
+def test_library_communicator_on_one_rank(native):
+    """The RCCL exchange behind the C ABI (mtr_comm_create, mtr_sharded_search_device,
+    mtr_comm_exchange_merge_device) on a one-rank communicator: local search ->
+    all-gather -> merge must give exactly what mtr_index_search_device gives, for
+    the fused call, the split (pipelined) form and changing shapes; a rank without
+    rows contributes padding only."""
+    import torch
+    from medical_rag_amd.sharded import ShardedIndex
+    comm = native.Comm.create(native.Comm.unique_id(), 0, 1, 0)
+    assert (comm.rank, comm.world, comm.device) == (0, 1, 0)
+    rng = np.random.default_rng(12)
+    n, d = 40000, 256
+    corpus = rng.standard_normal((n, d)).astype(np.float32)
+    shard = native.DeviceShard.from_host(corpus, store_dtype="bf16", row_offset=5000)
+    index = ShardedIndex(shard, comm=comm, always_exchange=True)
+    for b, k in ((1, 10), (7, 10), (1, 10), (40, 33), (3, 1), (130, 100)):
+        q = torch.from_numpy(rng.standard_normal((b, d)).astype(np.float32)).cuda()
+        want_i, want_s = (t.clone() for t in shard.search_device(q, k=k))
+        got_i, got_s = index.search_device(q, k=k)
+        torch.cuda.synchronize()
+        assert torch.equal(got_i, want_i) and torch.equal(got_s, want_s), (b, k)
+        pend = [index.search_device_async(q, k=k, depth=2) for _ in range(2)]
+        for p in pend:
+            pi, ps = p.result()
+            torch.cuda.synchronize()
+            assert torch.equal(pi, want_i) and torch.equal(ps, want_s), (b, k)
+    assert int(got_i.min()) >= 5000
+    # no rows on this rank: padding in, padding out
+    empty = ShardedIndex(None, comm=comm, always_exchange=True)
+    q = torch.from_numpy(rng.standard_normal((2, d)).astype(np.float32)).cuda()
+    ei, es = empty.search_device(q, k=4)
+    torch.cuda.synchronize()
+    assert (ei == -1).all() and torch.isneginf(es).all()
+    assert native.lib().mtr_comm_exchange_merge_device(comm._h, None, None, 0, 1, 1, None, None, None) == native.MTR_ERR_INVALID
+    assert native.lib().mtr_sharded_search_device(None, None, None, 0, 1, 1, 0, None, None, None) == native.MTR_ERR_INVALID
+    shard.close()
+    comm.close()
+
+
 def test_merge_reads_packed_gathered_buffer(native):
     """The exchange buffer layout of the multi-GPU path: every rank's ids and
     scores in one block, merged through strided views without copies."""

@@ -13,8 +13,9 @@ def test_shard_bounds_partition_the_rows(n, world):
     assert spans[0][0] == 0 and spans[-1][1] == n
     for (lo, hi), (lo2, _) in zip(spans, spans[1:]):
         assert 0 <= lo <= hi <= n and hi == lo2          # contiguous, ordered, no gap, no overlap
-    per = -(-n // world)
-    assert [hi - lo for lo, hi in spans] == [min(per, max(0, n - r * per)) for r in range(world)]  # blocks of ceil(n/world)
+    sizes = [hi - lo for lo, hi in spans]
+    assert sizes == [n // world + (1 if r < n % world else 0) for r in range(world)]   # balanced, longer blocks first
+    assert n < world or min(sizes) >= 1                                                # no empty rank unless n < world
 
 
 @given(b=st.integers(1, 9), k=st.integers(1, 17), blocks=st.integers(1, 5))
