@@ -79,7 +79,7 @@ hipError_t launch_read_rows(const void* rows, int dtype, int64_t n_rows, int d, 
 
 struct ScanPlan {
     int qb;          // queries per pass (1, 2, 4 or 8)
-    int nit;         // 64-lane sweeps per row
+    int nit;         // sweeps per row (16 lanes x 16 bytes each)
     int qstride;     // floats per padded query
     int grid;        // workgroups
     size_t lds;      // dynamic LDS bytes

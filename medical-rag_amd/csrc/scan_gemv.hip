@@ -6,17 +6,19 @@
 // re-normalisation of all rows, the dgemv and the argmax.
 //
 // Layout of the work
-//   - A wave owns groups of R consecutive rows (grid-strided, so a wave sees
-//     its rows in increasing order).  For each 64-lane sweep `it` of a row,
-//     lane l loads the 16-byte chunk  it*64 + l  of each of the R rows straight
-//     into registers (one coalesced 1 KiB wave-load per row and sweep, R loads
-//     in flight per wave, no LDS round trip for the rows).
+//   - Sixteen lanes share a row: one 64-lane load instruction fetches 256
+//     contiguous bytes of each of FOUR consecutive rows (lane l takes the
+//     16-byte chunk  s*16 + l%16  of row  l/16  in sweep s), straight into
+//     registers.  A wave owns groups of 8 consecutive rows (two such row
+//     quads, grid-strided, so a wave sees its rows in increasing order) and
+//     keeps 8 loads -- four sweeps of both quads, 1 KiB of each row -- in flight.
 //   - The QB queries of the pass live in LDS as zero-padded fp32; a lane reads
 //     the chunk that matches its row chunk, so chunks past the end of a row
 //     multiply by zero instead of being masked.
-//   - Each lane accumulates R*QB partial dot products; a butterfly exchange
-//     (halve the values, double the lanes summed) leaves every (row, query)
-//     total on its own lane after about R*QB cross-lane moves.
+//   - Each lane accumulates one partial dot product per (quad, query); the
+//     sixteen partial sums of a row are added with four DPP steps (lane
+//     permutes inside the VALU: no LDS crossbar traffic and no wait, which is
+//     what a 64-lane shuffle butterfly cost: 1 % of the scan's time).
 //   - Totals go to the wave's per-query top-k lists (wave_topk.h); the eight
 //     waves of a workgroup fold their lists pairwise
 //     at the end and the workgroup writes one sorted candidate list per query.
@@ -39,8 +41,10 @@ namespace {
 // (7.17 TB/s against 7.08 with sixteen waves, profiles/micro/read_patterns.hip),
 // and few workgroups keep the number of candidate lists (one each) small.
 constexpr int waves_per_group(int) { return 8; }
-// Rows per wave group: 8 for one or two queries, 4 beyond (register budget).
-constexpr int rows_per_group(int qb) { return qb <= 2 ? 8 : 4; }
+constexpr int kLanesPerRow = 16;   // lanes that share a row: 256 contiguous bytes per row and load
+constexpr int kQuads = 2;          // row quads per wave group: 8 rows
+constexpr int kSweepsPerBatch = 4; // sweeps of both quads requested together: 8 loads in flight per wave
+constexpr int kGroupRows = 4 * kQuads;
 
 template <bool NT>
 __device__ __forceinline__ u32x4 load_chunk(const u32x4* p) {
@@ -48,30 +52,18 @@ __device__ __forceinline__ u32x4 load_chunk(const u32x4* p) {
     else return *p;
 }
 
-template <int V>
-struct Log2 { static constexpr int value = 1 + Log2<V / 2>::value; };
-template <>
-struct Log2<1> { static constexpr int value = 0; };
-
-// After the call, lane l holds in vals[0] the sum over all 64 lanes of the
-// value whose index is  l >> (6 - log2 V).
-template <int V>
-__device__ __forceinline__ void butterfly_reduce(float (&vals)[V], int lane) {
-    constexpr int LOGV = Log2<V>::value;
-#pragma unroll
-    for (int s = 0; s < LOGV; ++s) {
-        const int mask = 32 >> s;
-        const int half = V >> (s + 1);
-        const bool upper = (lane & mask) != 0;
-#pragma unroll
-        for (int j = 0; j < half; ++j) {
-            const float keep = upper ? vals[j + half] : vals[j];
-            const float send = upper ? vals[j] : vals[j + half];
-            vals[j] = keep + __shfl_xor(send, mask, 64);
-        }
-    }
-#pragma unroll
-    for (int m = (32 >> LOGV); m >= 1; m >>= 1) vals[0] += __shfl_xor(vals[0], m, 64);
+// Sum over the sixteen lanes of a DPP row, left in every one of them: two
+// quad permutes (xor 1, xor 2), then rotations by 4 and by 8 lanes.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_move<0xB1>(v);    // quad_perm [1, 0, 3, 2]
+    v += dpp_move<0x4E>(v);    // quad_perm [2, 3, 0, 1]
+    v += dpp_move<0x124>(v);   // row_ror 4
+    v += dpp_move<0x128>(v);   // row_ror 8
+    return v;
 }
 
 struct ScanArgs {
@@ -79,14 +71,14 @@ struct ScanArgs {
     long long n;
     long long row_bytes;
     int nchunks;   // 16-byte chunks per row that hold data
-    int nit;       // sweeps per row = ceil(nchunks / 64)
+    int nit;       // sweeps per row = ceil(nchunks / 16)
     const float* q;       // prepared queries [QB][qstride] (used when q_raw is null)
     const float* q_raw;   // or: nb raw fp32 queries [nb][d], normalised and padded by every workgroup itself
     int d;
     int nb;
     int normalize;
     int* nonfinite_flag;  // set when a raw query holds NaN/inf
-    int qstride;   // floats per padded query = nit * 64 * EPC
+    int qstride;   // floats per padded query = nit * 16 * EPC
     int k;
     float* cand_s; // [QB][gridDim.x][k]
     int* cand_i;
@@ -96,9 +88,7 @@ template <typename T, int QB, bool NT>
 __global__ __launch_bounds__(waves_per_group(QB) * 64) void scan_topk_kernel(ScanArgs a) {
     constexpr int kWaves = waves_per_group(QB);
     constexpr int EPC = Chunk<T>::EPC;
-    constexpr int R = rows_per_group(QB);
-    constexpr int V = R * QB;
-    constexpr int LOGV = Log2<V>::value;
+    static_assert(kQuads * QB <= kLanesPerRow, "one lane of a row's sixteen per (quad, query) total");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* q_lds = reinterpret_cast<float*>(smem);
@@ -183,61 +173,82 @@ __global__ __launch_bounds__(waves_per_group(QB) * 64) void scan_topk_kernel(Sca
 #pragma unroll
     for (int b = 0; b < QB; ++b) tk[b].init(list_s + (wave * QB + b) * a.k, list_i + (wave * QB + b) * a.k, a.k);
 
-    const long long ngroups = (a.n + R - 1) / R;
+    const long long ngroups = (a.n + kGroupRows - 1) / kGroupRows;
     const long long gstride = (long long)gridDim.x * kWaves;
-    const int vidx = lane >> (6 - LOGV);
-    const int my_r = vidx / QB;
-    const int my_b = vidx % QB;
-    const bool owner = (lane & ((1 << (6 - LOGV)) - 1)) == 0;
+    const int col = lane & (kLanesPerRow - 1);   // this lane's chunk within a sweep
+    const int lrow = lane >> 4;                  // ... and its row within a quad
+    // The lane that reports the total of (quad, query): col = quad * QB + query.
+    const int my_quad = col / QB;
+    const int my_b = col % QB;
+    const bool owner = col < kQuads * QB;
 
     for (long long g = (long long)blockIdx.x * kWaves + wave; g < ngroups; g += gstride) {
-        const long long row0 = g * R;
-        const char* rp[R];
+        const long long row0 = g * kGroupRows;
+        const char* rp[kQuads];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            long long row = row0 + r;
+        for (int qd = 0; qd < kQuads; ++qd) {
+            long long row = row0 + qd * 4 + lrow;
             row = row < a.n ? row : a.n - 1;
-            rp[r] = a.rows + row * a.row_bytes;
+            rp[qd] = a.rows + row * a.row_bytes;
         }
-        float acc[V];
+        float acc[kQuads][QB];
 #pragma unroll
-        for (int v = 0; v < V; ++v) acc[v] = 0.f;
+        for (int qd = 0; qd < kQuads; ++qd)
+#pragma unroll
+            for (int b = 0; b < QB; ++b) acc[qd][b] = 0.f;
 
-        for (int it = 0; it < a.nit; ++it) {
-            const int chunk = it * 64 + lane;
-            // Chunks past the row's data read chunk 0 instead (always in
-            // bounds); their query values are zero.
-            const int chunk_c = chunk < a.nchunks ? chunk : 0;
-            u32x4 raw[R];
+        for (int s0 = 0; s0 < a.nit; s0 += kSweepsPerBatch) {
+            u32x4 raw[kSweepsPerBatch][kQuads];
 #pragma unroll
-            for (int r = 0; r < R; ++r)
-                raw[r] = load_chunk<NT>(reinterpret_cast<const u32x4*>(rp[r] + (size_t)chunk_c * 16));
-            float qv[QB][EPC];
+            for (int u = 0; u < kSweepsPerBatch; ++u) {
+                if (s0 + u < a.nit) {   // wave-uniform
+                    const int chunk = (s0 + u) * kLanesPerRow + col;
+                    // Chunks past the row's data read chunk 0 instead (always in
+                    // bounds); their query values are zero.
+                    const int chunk_c = chunk < a.nchunks ? chunk : 0;
+#pragma unroll
+                    for (int qd = 0; qd < kQuads; ++qd)
+                        raw[u][qd] = load_chunk<NT>(reinterpret_cast<const u32x4*>(rp[qd] + (size_t)chunk_c * 16));
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kSweepsPerBatch; ++u) {
+                if (s0 + u < a.nit) {
+                    const int chunk = (s0 + u) * kLanesPerRow + col;
+                    float qv[QB][EPC];
+#pragma unroll
+                    for (int b = 0; b < QB; ++b) {
+                        const f32x4* qp = reinterpret_cast<const f32x4*>(q_lds + (size_t)b * a.qstride + (size_t)chunk * EPC);
+#pragma unroll
+                        for (int e4 = 0; e4 < EPC / 4; ++e4) {
+                            const f32x4 t = qp[e4];
+                            qv[b][4 * e4 + 0] = t[0]; qv[b][4 * e4 + 1] = t[1];
+                            qv[b][4 * e4 + 2] = t[2]; qv[b][4 * e4 + 3] = t[3];
+                        }
+                    }
+#pragma unroll
+                    for (int qd = 0; qd < kQuads; ++qd) {
+                        float f[EPC];
+                        Chunk<T>::unpack(raw[u][qd], f);
+#pragma unroll
+                        for (int b = 0; b < QB; ++b) {
+#pragma unroll
+                            for (int e = 0; e < EPC; ++e) acc[qd][b] = __builtin_fmaf(f[e], qv[b][e], acc[qd][b]);
+                        }
+                    }
+                }
+            }
+        }
+
+        float total = 0.f;
+#pragma unroll
+        for (int qd = 0; qd < kQuads; ++qd)
 #pragma unroll
             for (int b = 0; b < QB; ++b) {
-                const f32x4* qp = reinterpret_cast<const f32x4*>(q_lds + (size_t)b * a.qstride + (size_t)chunk * EPC);
-#pragma unroll
-                for (int e4 = 0; e4 < EPC / 4; ++e4) {
-                    const f32x4 t = qp[e4];
-                    qv[b][4 * e4 + 0] = t[0]; qv[b][4 * e4 + 1] = t[1];
-                    qv[b][4 * e4 + 2] = t[2]; qv[b][4 * e4 + 3] = t[3];
-                }
+                const float t = row16_sum(acc[qd][b]);
+                if (my_quad == qd && my_b == b) total = t;
             }
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                float f[EPC];
-                Chunk<T>::unpack(raw[r], f);
-#pragma unroll
-                for (int b = 0; b < QB; ++b) {
-#pragma unroll
-                    for (int e = 0; e < EPC; ++e) acc[r * QB + b] = __builtin_fmaf(f[e], qv[b][e], acc[r * QB + b]);
-                }
-            }
-        }
-
-        butterfly_reduce<V>(acc, lane);
-        const float total = acc[0];
-        const long long row = row0 + my_r;
+        const long long row = row0 + my_quad * 4 + lrow;
         const bool valid = owner && row < a.n;
 #pragma unroll
         for (int b = 0; b < QB; ++b) tk[b].push(total, (int)row, valid && my_b == b);
@@ -336,8 +347,8 @@ int plan_scan(int dtype, int64_t n, int d, int ld, int b, int k, int num_cus, Sc
     const int epc = 16 / esize;
     if ((ld * esize) % 16 != 0 || ld < d || k < 1 || n < 1 || b < 1) return -1;
     const int nchunks = (d * esize + 15) / 16;
-    plan->nit = (nchunks + 63) / 64;
-    plan->qstride = plan->nit * 64 * epc;
+    plan->nit = (nchunks + kLanesPerRow - 1) / kLanesPerRow;
+    plan->qstride = plan->nit * kLanesPerRow * epc;
     int qb = 1;
     // Four queries per pass cost the least per query (measured); eight run out of registers.
     while (qb < b && qb < 4) qb *= 2;
@@ -354,8 +365,7 @@ int plan_scan(int dtype, int64_t n, int d, int ld, int b, int k, int num_cus, Sc
         occ = plan->nontemporal ? occupancy_qb<float, true>(qb, plan->lds) : occupancy_qb<float, false>(qb, plan->lds);
     else
         occ = plan->nontemporal ? occupancy_qb<bf16_t, true>(qb, plan->lds) : occupancy_qb<bf16_t, false>(qb, plan->lds);
-    const int rpg = rows_per_group(qb);
-    const long long ngroups = (n + rpg - 1) / rpg;
+    const long long ngroups = (n + kGroupRows - 1) / kGroupRows;
     const int kWaves = waves_per_group(qb);
     long long want = (ngroups + kWaves - 1) / kWaves;
     // Single query: one workgroup per CU measured best at every shard size (10M x
