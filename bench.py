@@ -291,6 +291,7 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    ceiling_ms = shard.read_ceiling(20) if (rank == 0 and batch == 1) else None
     n_launch, scan_ms = shard.scan_time()
     samples = sorted(shard.scan_samples())
     shard.profile(False)
@@ -348,6 +349,12 @@ def main():
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "kernel": kernel, "kernel_avg_ms": scan_avg_ms,
                     "launches_per_step": passes, "algorithmic_bytes_per_launch": local_bytes}
+        if roof["bound"] == "hbm" and ceiling_ms:
+            # the scan's loads alone (no arithmetic), measured in this run on this shard
+            roof["ceiling_measured"] = {"GBps": local_bytes / (ceiling_ms * 1e-3) / 1e9, "kernel_ms": ceiling_ms,
+                                        "frac_of_ceiling": ceiling_ms / scan_avg_ms,
+                                        "what": "scan_read_only_kernel: the single-query scan's access pattern, launch "
+                                                "shape and cache policy without its arithmetic, 20 launches"}
         if traffic is not None:
             roof["traffic_source"] = (f"{traffic_file}: separate rocprofv3 --pmc passes over this command, committed; "
                                       "not collected during this run")

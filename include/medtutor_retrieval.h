@@ -199,13 +199,21 @@ int mtr_index_scan_time(mtr_index_t* index, int32_t* n_launches, double* total_m
  * order) into out_ms, their full count into n_launches. */
 int mtr_index_scan_samples(mtr_index_t* index, float* out_ms, int32_t cap, int32_t* n_launches);
 
+/* Measurement aid: runs the single-query scan's loads WITHOUT its arithmetic
+ * over the shard (same rows per wave, sweeps, cache policy and launch shape)
+ * reps times and returns the average milliseconds by HIP events: what the
+ * memory system delivers to the scan's access pattern on this GPU, the ceiling
+ * beside which the scan's own time is reported.  No counterpart in the
+ * reference. */
+int mtr_index_read_ceiling(mtr_index_t* index, int32_t reps, float* avg_ms);
+
 void mtr_index_destroy(mtr_index_t* index);
 
 /* Process-wide launch-shape switches, for parity tests (which force the
  * kernel forms of large shards onto small ones) and timing sweeps; not needed
  * for normal use.  Names: mfma_min_batch, mfma_tnq, mfma_per_cu, mfma_cap,
  * mfma_sample_stride, mfma_stream_rows, mfma_stages, mfma_tile_rows,
- * wide_min_batch, scan_wg_per_cu, scan_nontemporal.  Each starts from the
+ * wide_min_batch, scan_wg_per_cu, scan_nontemporal, pool_sliced.  Each starts from the
  * environment variable MTR_<NAME> if set.  Unknown name: MTR_ERR_INVALID.
  * No counterpart in the reference. */
 int mtr_tuning_set(const char* name, int32_t value);

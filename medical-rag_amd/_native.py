@@ -50,6 +50,7 @@ SIGNATURES = {
     "mtr_index_scan_samples": (_i32, [_vp, C.POINTER(C.c_float), _i32, C.POINTER(_i32)]),
     "mtr_tuning_set": (_i32, [C.c_char_p, _i32]),
     "mtr_tuning_get": (_i32, [C.c_char_p, C.POINTER(_i32)]),
+    "mtr_index_read_ceiling": (_i32, [_vp, _i32, C.POINTER(C.c_float)]),
     "mtr_index_destroy": (None, [_vp]),
     "mtr_last_error": (C.c_char_p, []),
     "mtr_version": (C.c_char_p, []),
@@ -316,6 +317,12 @@ class DeviceShard:
         buf = (C.c_float * max(n.value, 1))()
         check(lib().mtr_index_scan_samples(self._h, buf, n.value, C.byref(n)))
         return [buf[i] for i in range(n.value)]
+
+    def read_ceiling(self, reps=20) -> float:
+        """Average milliseconds of the scan's loads alone over this shard (mtr_index_read_ceiling)."""
+        ms = C.c_float()
+        check(lib().mtr_index_read_ceiling(self._h, int(reps), C.byref(ms)))
+        return ms.value
 
     def close(self):
         if self._h is not None and self._h.value:

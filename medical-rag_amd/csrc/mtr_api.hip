@@ -737,7 +737,7 @@ int mtr_pool_normalize(const void* dev_hidden, int32_t dtype, const int64_t* dev
                        int32_t d, float* dev_out, int32_t device_id, void* stream) {
     if (!dev_hidden || !dev_mask || !dev_out) return fail(MTR_ERR_INVALID, "NULL argument");
     if (dtype != MTR_F32 && dtype != MTR_BF16 && dtype != MTR_F16) return fail(MTR_ERR_INVALID, "bad dtype %d", dtype);
-    if (b < 1 || t < 1 || d < 1 || d > 8192) return fail(MTR_ERR_INVALID, "bad shape (b=%d, t=%d, d=%d)", b, t, d);
+    if (b < 1 || t < 1 || d < 1) return fail(MTR_ERR_INVALID, "bad shape (b=%d, t=%d, d=%d)", b, t, d);
     DeviceGuard guard(device_id);
     if (!guard.ok) return fail(MTR_ERR_HIP, "hipSetDevice(%d) failed", device_id);
     HIP_TRY(mtr::launch_pool_normalize(dev_hidden, dtype, reinterpret_cast<const long long*>(dev_mask), b, t, d, dev_out,
@@ -817,6 +817,37 @@ int mtr_index_scan_samples(mtr_index_t* ix, float* out_ms, int32_t cap, int32_t*
     return MTR_OK;
 }
 
+int mtr_index_read_ceiling(mtr_index_t* ix, int32_t reps, float* avg_ms) {
+    int rc = check_index(ix);
+    if (rc != MTR_OK) return rc;
+    if (reps < 1 || !avg_ms) return fail(MTR_ERR_INVALID, "reps must be >= 1 and avg_ms not NULL");
+    std::lock_guard<std::mutex> lock(ix->mu);
+    DeviceGuard guard(ix->device);
+    mtr::ScanPlan plan;
+    if (mtr::plan_scan(ix->dtype, ix->n, ix->d, ix->ld, 1, 1, ix->num_cus, &plan) != 0)
+        return fail(MTR_ERR_INVALID, "no scan shape for this shard");
+    if ((rc = begin_use(ix, ix->stream)) != MTR_OK) return rc;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    unsigned int* sink = reinterpret_cast<unsigned int*>(ix->flag) + 8;   // spare words of the flag block
+    double sum = 0.0;
+    for (int r = 0; r < reps + 1; ++r) {   // the first launch warms up
+        HIP_TRY(hipEventRecord(e0, ix->stream));
+        HIP_TRY(mtr::launch_scan_read_only(ix->rows, ix->dtype, ix->n, ix->ld, ix->d, plan, sink, ix->stream));
+        HIP_TRY(hipEventRecord(e1, ix->stream));
+        HIP_TRY(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        if (r > 0) sum += ms;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if ((rc = end_use(ix, ix->stream)) != MTR_OK) return rc;
+    *avg_ms = (float)(sum / reps);
+    return MTR_OK;
+}
+
 void mtr_index_destroy(mtr_index_t* ix) {
     if (!ix) return;
     {
@@ -857,7 +888,7 @@ const TuningField kTuningFields[] = {
     {"mfma_sample_stride", &mtr::Tuning::mfma_sample_stride}, {"mfma_stream_rows", &mtr::Tuning::mfma_stream_rows},
     {"mfma_stages", &mtr::Tuning::mfma_stages},           {"mfma_tile_rows", &mtr::Tuning::mfma_tile_rows},
     {"wide_min_batch", &mtr::Tuning::wide_min_batch},     {"scan_wg_per_cu", &mtr::Tuning::scan_wg_per_cu},
-    {"scan_nontemporal", &mtr::Tuning::scan_nontemporal},
+    {"scan_nontemporal", &mtr::Tuning::scan_nontemporal}, {"pool_sliced", &mtr::Tuning::pool_sliced},
 #ifdef MTR_TIMING_SWITCHES
     {"timing_mfma", &mtr::Tuning::timing_mfma},           {"timing_wide", &mtr::Tuning::timing_wide},
 #endif

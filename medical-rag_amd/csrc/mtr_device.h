@@ -58,6 +58,7 @@ struct Tuning {
     int wide_min_batch = 129;     // smallest batch for the 256 x 256-tile kernel
     int scan_wg_per_cu = 0;       // scan workgroups per CU (0: one for a single query, occupancy otherwise)
     int scan_nontemporal = -1;    // -1: streaming row loads on shards beyond the caches; 0 / 1
+    int pool_sliced = -1;         // pooling kernel form: -1 by shape (two kernels from 256 tokens); 0 one kernel; 1 two kernels
     int timing_mfma = 0;          // MTR_TIMING_SWITCHES builds only: drop candidates / skip loads or MFMAs (wrong results)
     int timing_wide = 0;          // MTR_TIMING_SWITCHES builds only
     float timing_floor = 0.f;     // MTR_TIMING_SWITCHES builds only
@@ -114,6 +115,11 @@ hipError_t launch_merge_topk(const float* cand_s, const int* idx32, const long l
 // hidden [b][t][d] (dtype 0 fp32, 2 bf16, 3 fp16), mask [b][t] int64 -> out [b][d] fp32.
 hipError_t launch_pool_normalize(const void* hidden, int dtype, const long long* mask, int b, int t, int d, float* out,
                                  hipStream_t stream);
+
+// The single-query scan's loads without its arithmetic (plan from plan_scan with b = 1): a
+// live measurement of what the memory system delivers to the scan's access pattern.
+hipError_t launch_scan_read_only(const void* rows, int dtype, int64_t n, int ld, int d, const ScanPlan& plan,
+                                 unsigned int* sink, hipStream_t stream);
 
 struct MfmaPlan {
     int cap;                  // candidate slots per (workgroup, query): 256 or 512

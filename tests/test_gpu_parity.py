@@ -805,6 +805,67 @@ def test_pool_normalize_matches_torch(native, dtype):
         torch.testing.assert_close(got, want, atol=2e-6, rtol=1e-5)
 
 
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16", "float16"])
+def test_pool_normalize_long_sequences_take_the_sliced_form(native, dtype):
+    """Index pages run to thousands of tokens: the pooling is then cut over token
+    slices and column blocks (two kernels).  Against the reference's torch
+    expression, against the one-kernel form, on widths beyond its 8192 columns
+    and on rows that are not a multiple of 16 bytes."""
+    import torch
+    torch.manual_seed(11)
+    for b, t, d in ((3, 2048, 1024), (2, 700, 4096), (1, 300, 9000), (2, 260, 1001), (4, 40, 10000)):
+        h = torch.randn(b, t, d, device="cuda").to(getattr(torch, dtype))
+        lengths = torch.randint(1, t + 1, (b,), device="cuda")
+        lengths[0] = t
+        mask = (torch.arange(t, device="cuda")[None, :] < lengths[:, None]).long()   # right padding, as the tokenizer pads
+        if b > 1:
+            mask[1, ::3] = 0                                                        # holes as well
+        got = native.pool_normalize(h, mask)
+        hf = h.float()
+        m = mask.unsqueeze(-1).expand(hf.size()).float()
+        want = torch.nn.functional.normalize((hf * m).sum(1) / torch.clamp(m.sum(1), min=1e-9), p=2, dim=1)
+        assert torch.isfinite(got).all()
+        torch.testing.assert_close(got, want, atol=2e-6, rtol=1e-5)
+        if d <= 8192:
+            with native.options(pool_sliced=0):
+                one = native.pool_normalize(h, mask)
+            with native.options(pool_sliced=1):
+                two = native.pool_normalize(h, mask)
+            torch.testing.assert_close(one, two, atol=2e-6, rtol=1e-5)
+            assert torch.equal(two, got) or torch.equal(one, got)
+
+
+def test_index_builder_on_gpu(rag, golden, tmp_path):
+    """The index builder with the encoder on the GPU (pooling in the HIP kernel):
+    same vectors as the reference's builder produced for the fixture, the JSON it
+    writes is the reference's schema, and the sidecar loads and searches."""
+    import json
+    import os
+    from medical_rag_amd import index_builder
+    a, e = golden("g7_encoder")
+    tiny = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tiny_encoder")
+    splits = tmp_path / "ocr_batches"
+    splits.mkdir()
+    (splits / "split_1.json").write_text(json.dumps({"pages": e["pages_in"][:3]}))
+    (splits / "split_2.json").write_text(json.dumps({"pages": e["pages_in"][3:]}))
+    report = index_builder.build(str(splits / "split_*.json"), tiny, "cuda", str(tmp_path), batch_size=2)
+    assert report["pages"] == len(e["pages_in"]) and report["embedded"] == len(e["pages_in"]) and report["failed"] == []
+    written = json.load(open(report["path"]))
+    assert [{k: v for k, v in p.items() if k != "embedding"} for p in written] == e["pages_out"]
+    vectors = np.array([p["embedding"] for p in written])
+    np.testing.assert_allclose(vectors, a["page_vectors"], atol=2e-5, rtol=0)
+    index = rag.load_embeddings(report["path"])           # the sidecar the builder wrote
+    assert len(index) == len(written) and list(index) == e["pages_out"]
+    idx, score = index.search(a["page_vectors"], k=1)
+    assert idx[:, 0].tolist() == list(range(len(written)))
+    np.testing.assert_allclose(score[:, 0], 1.0, atol=1e-5)
+    # the same pages through the two-kernel (token-sliced) pooling form that long pages take
+    from medical_rag_amd import _native
+    with _native.options(pool_sliced=1):
+        sliced = index_builder.generate_embeddings_hf(e["pages_in"], tiny, "cuda", batch_size=2)
+    np.testing.assert_allclose(np.array([p["embedding"] for p in sliced]), a["page_vectors"], atol=2e-5, rtol=0)
+
+
 def test_embed_queries_on_gpu_matches_reference(rag, golden):
     """Encoder forward in PyTorch-ROCm, pooling + normalisation in the HIP kernel."""
     import os
