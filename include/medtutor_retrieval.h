@@ -47,6 +47,11 @@ enum {
 };
 
 enum { MTR_F32 = 0, MTR_F64 = 1, MTR_BF16 = 2, MTR_F16 = 3 /* mtr_pool_normalize input only */ };
+/* OR-ed into mtr_index_load_rows' src_dtype: the rows are already in the
+ * shard's stored form (unit length or zero when the shard is normalised), e.g.
+ * read back from a bf16 index file: they are checked for NaN/inf, cast and
+ * padded, but not normalised again (a second rounding would change them). */
+enum { MTR_ROWS_AS_STORED = 256 };
 enum { MTR_COSINE = 0, MTR_IP = 1 };
 
 #define MTR_MAX_K 1024

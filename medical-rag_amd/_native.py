@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 MTR_OK, MTR_ERR_INVALID, MTR_ERR_NONFINITE, MTR_ERR_HIP, MTR_ERR_COMM, MTR_ERR_OOM = 0, -1, -2, -3, -4, -5
 MTR_F32, MTR_F64, MTR_BF16, MTR_F16 = 0, 1, 2, 3
+MTR_ROWS_AS_STORED = 256
 MTR_COSINE, MTR_IP = 0, 1
 MTR_MAX_K = 1024
 
@@ -131,6 +132,8 @@ class options:
 
 
 def np_dtype_code(a: np.ndarray) -> int:
+    if a.dtype == np.uint16:      # raw bfloat16 bits (numpy has no bfloat16)
+        return MTR_BF16
     if a.dtype == np.float32:
         return MTR_F32
     if a.dtype == np.float64:
@@ -153,6 +156,10 @@ def as_host_matrix(a, name="array") -> np.ndarray:
     """C-contiguous float32/float64 2-D view of `a` (1-D becomes one row)."""
     if not isinstance(a, np.ndarray):
         a = np.asarray(a)
+    if a.dtype == np.uint16 and name == "rows":   # bfloat16 bits, as a bf16 index file stores them
+        if a.ndim != 2:
+            raise ValueError("bfloat16 rows must be 2-D")
+        return np.ascontiguousarray(a)
     if a.dtype not in (np.float32, np.float64):
         a = a.astype(np.float64 if a.dtype.kind in "iu" or a.dtype.itemsize > 4 else np.float32)
     if a.ndim == 1:
@@ -179,20 +186,26 @@ class DeviceShard:
         return cls(out)
 
     @classmethod
-    def from_host(cls, rows, store_dtype="fp32", normalize=True, device=0, row_offset=0):
+    def from_host(cls, rows, store_dtype="fp32", normalize=True, device=0, row_offset=0, as_stored=False):
+        """rows: (n, d) float32 / float64, or uint16 holding bfloat16 bits.
+        as_stored: the rows are already unit length (read back from an index
+        file written from a shard): they are not normalised a second time."""
         rows = as_host_matrix(rows, "rows")
-        out = C.c_void_p()
-        check(lib().mtr_index_create(rows.ctypes.data_as(C.c_void_p), rows.shape[0], rows.shape[1],
-                                     np_dtype_code(rows), STORE_DTYPES[store_dtype], int(bool(normalize)),
-                                     int(device), int(row_offset), C.byref(out)))
-        return cls(out)
+        shard = cls.alloc(rows.shape[0], rows.shape[1], store_dtype=store_dtype, normalize=normalize, device=device,
+                          row_offset=row_offset)
+        try:
+            shard.load_host(0, rows, as_stored=as_stored)
+        except Exception:
+            shard.close()
+            raise
+        return shard
 
-    def load_host(self, row_start, rows):
+    def load_host(self, row_start, rows, as_stored=False):
         rows = as_host_matrix(rows, "rows")
         if rows.shape[1] != self.d:
             raise ValueError(f"rows have {rows.shape[1]} columns, shard has {self.d}")
-        check(lib().mtr_index_load_rows(self._h, int(row_start), rows.ctypes.data_as(C.c_void_p), rows.shape[0],
-                                        np_dtype_code(rows), 0))
+        code = np_dtype_code(rows) | (MTR_ROWS_AS_STORED if as_stored else 0)
+        check(lib().mtr_index_load_rows(self._h, int(row_start), rows.ctypes.data_as(C.c_void_p), rows.shape[0], code, 0))
 
     def load_device(self, row_start, tensor):
         """tensor: contiguous (rows, d) torch tensor on this shard's GPU."""
@@ -292,6 +305,19 @@ class DeviceShard:
         flag = _i32()
         check(lib().mtr_index_nonfinite(self._h, C.byref(flag)))
         return bool(flag.value)
+
+    def read_rows_bf16(self, row_start=0, n_rows=None, chunk_rows=65536):
+        """The stored rows of a bf16 shard as uint16 bfloat16 bits (exact)."""
+        inf = self.info()
+        if inf["store_dtype"] != "bf16":
+            raise ValueError("read_rows_bf16 needs a bf16 shard")
+        if n_rows is None:
+            n_rows = inf["n"] - row_start
+        out = np.empty((n_rows, inf["d"]), dtype=np.uint16)
+        for r0 in range(0, n_rows, chunk_rows):
+            part = self.read_rows(row_start + r0, min(chunk_rows, n_rows - r0))
+            out[r0:r0 + len(part)] = (part.view(np.uint32) >> 16).astype(np.uint16)   # fp32 of a bf16 value: low half zero
+        return out
 
     def read_rows(self, row_start=0, n_rows=None):
         inf = self.info()

@@ -11,7 +11,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .local_rag import get_surrounding_pages, search
+from .local_rag import _SETTINGS, get_surrounding_pages, search
 
 
 def unique_keywords(cases) -> list:
@@ -21,9 +21,12 @@ def unique_keywords(cases) -> list:
                    if isinstance(kw, str) and kw.strip()})
 
 
-def top_pages_for_keywords(kw_embeddings_map: dict, pages, top_k: int = 1) -> dict:
+def top_pages_for_keywords(kw_embeddings_map: dict, pages, top_k: int | None = None) -> dict:
     """One batched search for every keyword that has a non-empty vector:
-    keyword -> (idx (top_k,), score (top_k,))."""
+    keyword -> (idx (top_k,), score (top_k,)).  top_k None: the configured
+    local_top_k (default 1)."""
+    if top_k is None:
+        top_k = _SETTINGS["top_k"]
     usable = [(kw, np.asarray(v)) for kw, v in kw_embeddings_map.items() if v is not None and np.asarray(v).size > 0]
     if not usable or len(pages) == 0:
         return {}
@@ -44,13 +47,21 @@ def top_pages_for_texts(keywords: list, model_name: str, device: str, pages, top
         return {}
     idx, score = search(pages, vectors, k=top_k)
     idx, score = idx.cpu().numpy(), score.cpu().numpy()
+    # the device path cannot fail a call it does not wait for; after the copy above it can be asked
+    shard = getattr(pages, "shard", None)
+    if shard is not None and shard.nonfinite():
+        raise ValueError("Input contains NaN or infinity.")   # what sklearn raises at pipeline/utils/local_rag.py:77
     return {kw: (idx[i], score[i]) for i, kw in enumerate(keywords)}
 
 
-def local_pages_for_cases(cases, kw_embeddings_map: dict, pages, window_size: int = 1, hits: dict | None = None) -> list:
+def local_pages_for_cases(cases, kw_embeddings_map: dict, pages, window_size: int | None = None,
+                          hits: dict | None = None) -> list:
     """For every case the dict the reference stores as "local_pages_per_keyword"
     (pipeline/utils/retrieval.py:70-76, 82): keyword -> hit page with its
-    neighbours, vectors stripped."""
+    neighbours, vectors stripped.  window_size None: the configured window
+    (local_window, default 1 as in the reference)."""
+    if window_size is None:
+        window_size = _SETTINGS["window"]
     if hits is None:
         hits = top_pages_for_keywords(kw_embeddings_map, pages, top_k=1)
     out = []

@@ -1,0 +1,83 @@
+// Host-side exerciser of the C ABI for the sanitizer build (make asan): every
+// entry point is called with invalid and boundary arguments, and, when a GPU is
+// present, a small index goes through create / search / read back / destroy.
+// It needs no GPU to be useful: without one every device call must fail with an
+// error code and a message, never with a crash or a leak.
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/medtutor_retrieval.h"
+
+static int failures = 0;
+#define EXPECT(cond)                                                       \
+    do {                                                                   \
+        if (!(cond)) {                                                     \
+            ++failures;                                                    \
+            fprintf(stderr, "abi_check: %s failed at line %d (last error: %s)\n", #cond, __LINE__, mtr_last_error()); \
+        }                                                                  \
+    } while (0)
+
+int main() {
+    printf("%s\n", mtr_version());
+    mtr_index_t* ix = nullptr;
+    EXPECT(mtr_index_alloc(0, 8, MTR_F32, 1, 0, 0, &ix) == MTR_ERR_INVALID && ix == nullptr);
+    EXPECT(strlen(mtr_last_error()) > 0);
+    EXPECT(mtr_index_alloc(8, 8, 7, 1, 0, 0, &ix) == MTR_ERR_INVALID);
+    EXPECT(mtr_index_alloc(8, 8, MTR_F32, 1, 0, 0, nullptr) == MTR_ERR_INVALID);
+    EXPECT(mtr_index_search(nullptr, nullptr, 0, 0, 1, 1, 0, nullptr, nullptr) == MTR_ERR_INVALID);
+    EXPECT(mtr_index_search_device(nullptr, nullptr, 0, 1, 1, 0, nullptr, nullptr, nullptr) == MTR_ERR_INVALID);
+    EXPECT(mtr_index_search_device_noalloc(nullptr, nullptr, 0, 1, 1, 0, nullptr, nullptr, nullptr) == MTR_ERR_INVALID);
+    EXPECT(mtr_index_info(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr) == MTR_ERR_INVALID);
+    EXPECT(mtr_index_load_rows(nullptr, 0, nullptr, 0, 0, 0) == MTR_ERR_INVALID);
+    EXPECT(mtr_index_read_rows(nullptr, 0, 0, nullptr) == MTR_ERR_INVALID);
+    EXPECT(mtr_index_nonfinite(nullptr, nullptr) == MTR_ERR_INVALID);
+    EXPECT(mtr_index_profile(nullptr, 1) == MTR_ERR_INVALID);
+    EXPECT(mtr_index_read_ceiling(nullptr, 1, nullptr) == MTR_ERR_INVALID);
+    EXPECT(mtr_merge_topk_device(nullptr, nullptr, 1, 0, 0, 1, 1, 1, nullptr, nullptr, 0, nullptr) == MTR_ERR_INVALID);
+    EXPECT(mtr_pool_normalize(nullptr, 0, nullptr, 1, 1, 1, nullptr, 0, nullptr) == MTR_ERR_INVALID);
+    EXPECT(mtr_comm_create(nullptr, 0, 1, 0, nullptr) == MTR_ERR_INVALID);
+    mtr_comm_t* comm = nullptr;
+    EXPECT(mtr_comm_create(nullptr, 0, 1, 0, &comm) == MTR_ERR_INVALID && comm == nullptr);
+    EXPECT(mtr_comm_exchange_merge_device(nullptr, nullptr, nullptr, 1, 1, 1, nullptr, nullptr, nullptr) == MTR_ERR_INVALID);
+    EXPECT(mtr_sharded_search_device(nullptr, nullptr, nullptr, 0, 1, 1, 0, nullptr, nullptr, nullptr) == MTR_ERR_INVALID);
+    mtr_comm_destroy(nullptr);
+    mtr_index_destroy(nullptr);
+    int32_t v = -7;
+    EXPECT(mtr_tuning_get("wide_min_batch", &v) == MTR_OK && v == 129);
+    EXPECT(mtr_tuning_set("wide_min_batch", 200) == MTR_OK && mtr_tuning_get("wide_min_batch", &v) == MTR_OK && v == 200);
+    EXPECT(mtr_tuning_set("wide_min_batch", 129) == MTR_OK);
+    EXPECT(mtr_tuning_set("no_such_switch", 1) == MTR_ERR_INVALID);
+    EXPECT(mtr_tuning_get(nullptr, &v) == MTR_ERR_INVALID);
+
+    // With a GPU: one small index end to end; without: a clean error.
+    const int n = 300, d = 40, b = 3, k = 5;
+    std::vector<float> rows((size_t)n * d), q((size_t)b * d);
+    for (size_t i = 0; i < rows.size(); ++i) {   // a hash of i: no two rows alike
+        uint32_t x = (uint32_t)i * 2654435761u + 0x9e3779b9u;
+        x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
+        rows[i] = (float)(x % 2001) / 1000.f - 1.f;
+    }
+    for (int j = 0; j < b; ++j) memcpy(&q[(size_t)j * d], &rows[(size_t)(17 * j + 5) * d], d * sizeof(float));
+    int rc = mtr_index_create(rows.data(), n, d, MTR_F32, MTR_F32, 1, 0, 0, &ix);
+    if (rc == MTR_OK) {
+        std::vector<int64_t> idx((size_t)b * k);
+        std::vector<float> score((size_t)b * k);
+        EXPECT(mtr_index_search(ix, q.data(), MTR_F32, 0, b, k, MTR_COSINE, idx.data(), score.data()) == MTR_OK);
+        for (int j = 0; j < b; ++j) EXPECT(idx[(size_t)j * k] == 17 * j + 5);
+        EXPECT(mtr_index_search(ix, q.data(), MTR_F32, 0, b, MTR_MAX_K + 1, MTR_COSINE, idx.data(), score.data()) == MTR_ERR_INVALID);
+        std::vector<float> back((size_t)2 * d);
+        EXPECT(mtr_index_read_rows(ix, 1, 2, back.data()) == MTR_OK);
+        EXPECT(mtr_index_read_rows(ix, n - 1, 2, back.data()) == MTR_ERR_INVALID);
+        q[3] = 1.0f / 0.0f;
+        EXPECT(mtr_index_search(ix, q.data(), MTR_F32, 0, b, k, MTR_COSINE, idx.data(), score.data()) == MTR_ERR_NONFINITE);
+        mtr_index_destroy(ix);
+        printf("abi_check: GPU path exercised\n");
+    } else {
+        EXPECT(ix == nullptr && strlen(mtr_last_error()) > 0);
+        printf("abi_check: no usable GPU (%s); argument checks only\n", mtr_last_error());
+    }
+    printf("abi_check: %d failure(s)\n", failures);
+    return failures ? 1 : 0;
+}

@@ -546,7 +546,7 @@ namespace {
 
 // Host rows -> shard through page-locked staging: the host copy of chunk i + 1
 // into its pinned buffer runs while chunk i crosses PCIe and is converted.
-int upload_host_rows(mtr_index* ix, int64_t row_start, const char* rows, int64_t n_rows, int src_dtype) {
+int upload_host_rows(mtr_index* ix, int64_t row_start, const char* rows, int64_t n_rows, int src_dtype, int normalize) {
     int rc;
     const size_t esize = dtype_size(ix->dtype);
     const size_t src_row = (size_t)ix->d * dtype_size(src_dtype);
@@ -574,7 +574,7 @@ int upload_host_rows(mtr_index* ix, int64_t row_start, const char* rows, int64_t
         memcpy(ix->pinned[i], rows + (size_t)r0 * src_row, (size_t)nr * src_row);
         HIP_TRY(hipMemcpyAsync(ix->stage[i].p, ix->pinned[i], (size_t)nr * src_row, hipMemcpyHostToDevice, ix->stream));
         char* dst = static_cast<char*>(ix->rows) + (size_t)(row_start + r0) * ix->ld * esize;
-        HIP_TRY(mtr::launch_load_rows(ix->stage[i].p, src_dtype, nr, ix->d, dst, ix->dtype, ix->ld, ix->normalized,
+        HIP_TRY(mtr::launch_load_rows(ix->stage[i].p, src_dtype, nr, ix->d, dst, ix->dtype, ix->ld, normalize,
                                       ix->flag, ix->stream));
         HIP_TRY(hipEventRecord(ix->stage_done[i], ix->stream));
     }
@@ -588,6 +588,8 @@ int mtr_index_load_rows(mtr_index_t* ix, int64_t row_start, const void* rows, in
     int rc = check_index(ix);
     if (rc != MTR_OK) return rc;
     if (!rows && n_rows > 0) return fail(MTR_ERR_INVALID, "rows is NULL");
+    const int normalize = (src_dtype & MTR_ROWS_AS_STORED) ? 0 : ix->normalized;
+    src_dtype &= ~MTR_ROWS_AS_STORED;
     const int ssize = dtype_size(src_dtype);
     if (!ssize) return fail(MTR_ERR_INVALID, "bad src_dtype %d", src_dtype);
     if (row_start < 0 || n_rows < 0 || row_start + n_rows > ix->n)
@@ -601,9 +603,9 @@ int mtr_index_load_rows(mtr_index_t* ix, int64_t row_start, const void* rows, in
         // nothing to convert
     } else if (rows_on_device) {
         char* dst = static_cast<char*>(ix->rows) + (size_t)row_start * ix->ld * dtype_size(ix->dtype);
-        HIP_TRY(mtr::launch_load_rows(rows, src_dtype, n_rows, ix->d, dst, ix->dtype, ix->ld, ix->normalized, ix->flag,
+        HIP_TRY(mtr::launch_load_rows(rows, src_dtype, n_rows, ix->d, dst, ix->dtype, ix->ld, normalize, ix->flag,
                                       ix->stream));
-    } else if ((rc = upload_host_rows(ix, row_start, static_cast<const char*>(rows), n_rows, src_dtype)) != MTR_OK) {
+    } else if ((rc = upload_host_rows(ix, row_start, static_cast<const char*>(rows), n_rows, src_dtype, normalize)) != MTR_OK) {
         (void)hipStreamSynchronize(ix->stream);
         return rc;
     }

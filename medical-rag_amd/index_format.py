@@ -12,10 +12,16 @@ and streamed to the GPU in chunks.
     <index>.json.mtr      header (64 bytes) + n*d float32, C order
     <index>.json.pages    JSON list of the page dicts without "embedding"
 
-Header: magic "MTRIDX1\\0", u64 n, u32 d, u32 dtype (0 = fp32), u64 size and
-i64 mtime_ns of the JSON the sidecar was made from (0/0 when built without
-one), 24 bytes reserved.  A sidecar whose recorded size/mtime do not match its
-JSON is stale and ignored.
+Header: magic "MTRIDX1\\0", u64 n, u32 d, u32 dtype (0 = fp32, 2 = bfloat16
+bits), u64 size and i64 mtime_ns of the JSON the sidecar was made from (0/0
+when built without one), u32 flags (bit 0: the rows are stored as a shard
+holds them, L2-normalised and rounded, and load without a second
+normalisation), 20 bytes reserved.  A sidecar whose recorded size/mtime do not
+match its JSON is stale and ignored.
+
+A bf16 sidecar is half the bytes on disk and over PCIe (100M x 768: 154 GB
+instead of 307 GB); it is written from a device shard (the loader's own
+normalisation and rounding), so loading it reproduces that shard bit for bit.
 """
 from __future__ import annotations
 
@@ -26,7 +32,9 @@ import struct
 import numpy as np
 
 MAGIC = b"MTRIDX1\0"
-HEADER = struct.Struct("<8sQIIQq24x")
+HEADER = struct.Struct("<8sQIIQqI20x")
+DTYPE_F32, DTYPE_BF16 = 0, 2
+FLAG_AS_STORED = 1
 assert HEADER.size == 64
 
 
@@ -34,9 +42,16 @@ def sidecar_paths(json_path: str):
     return json_path + ".mtr", json_path + ".pages"
 
 
-def write_sidecar(json_path: str, matrix: np.ndarray, pages_meta: list, bind_to_source: bool = True):
-    """Writes <json_path>.mtr / .pages for an (n, d) matrix and its page dicts."""
-    matrix = np.ascontiguousarray(matrix, dtype=np.float32)
+def write_sidecar(json_path: str, matrix: np.ndarray, pages_meta: list, bind_to_source: bool = True,
+                  as_stored: bool = False):
+    """Writes <json_path>.mtr / .pages for an (n, d) matrix and its page dicts.
+    float matrices are stored as fp32; a uint16 matrix is bfloat16 bits (as
+    DeviceShard.read_rows_bf16 returns them).  as_stored: the rows are a shard's
+    stored rows and must not be normalised again on load."""
+    if isinstance(matrix, np.ndarray) and matrix.dtype == np.uint16:
+        matrix, dtype = np.ascontiguousarray(matrix), DTYPE_BF16
+    else:
+        matrix, dtype = np.ascontiguousarray(matrix, dtype=np.float32), DTYPE_F32
     if matrix.ndim != 2 or len(pages_meta) != matrix.shape[0]:
         raise ValueError("matrix must be (n, d) with one page dict per row")
     size = mtime = 0
@@ -46,7 +61,8 @@ def write_sidecar(json_path: str, matrix: np.ndarray, pages_meta: list, bind_to_
     mtr, pages = sidecar_paths(json_path)
     tmp = mtr + ".tmp"
     with open(tmp, "wb") as f:
-        f.write(HEADER.pack(MAGIC, matrix.shape[0], matrix.shape[1], 0, size, mtime))
+        f.write(HEADER.pack(MAGIC, matrix.shape[0], matrix.shape[1], dtype, size, mtime,
+                            FLAG_AS_STORED if as_stored else 0))
         matrix.tofile(f)
     os.replace(tmp, mtr)
     tmp = pages + ".tmp"
@@ -56,14 +72,23 @@ def write_sidecar(json_path: str, matrix: np.ndarray, pages_meta: list, bind_to_
     return mtr, pages
 
 
-def convert(json_path: str):
-    """Parses the reference's JSON index once and writes its sidecar."""
+def convert(json_path: str, store_dtype: str = "fp32", device: int | None = None):
+    """Parses the reference's JSON index once and writes its sidecar.
+    store_dtype "bf16": the rows go through a bf16 shard on the GPU first and
+    the sidecar holds exactly what that shard stores (needs the GPU)."""
     with open(json_path, "r", encoding="utf-8") as f:
         pages = json.load(f)
     if not pages:
         raise ValueError("empty index")
     matrix = np.array([p["embedding"] for p in pages], dtype=np.float32)
     meta = [{k: v for k, v in p.items() if k != "embedding"} for p in pages]
+    if store_dtype in ("bf16", "bfloat16"):
+        from . import _native
+        shard = _native.DeviceShard.from_host(matrix, store_dtype="bf16", normalize=True, device=device or 0)
+        try:
+            return write_sidecar(json_path, shard.read_rows_bf16(), meta, as_stored=True)
+        finally:
+            shard.close()
     return write_sidecar(json_path, matrix, meta)
 
 
@@ -72,17 +97,19 @@ def read_header(mtr_path: str):
         raw = f.read(HEADER.size)
     if len(raw) != HEADER.size:
         raise ValueError("truncated sidecar header")
-    magic, n, d, dtype, size, mtime = HEADER.unpack(raw)
+    magic, n, d, dtype, size, mtime, flags = HEADER.unpack(raw)
     if magic != MAGIC:
         raise ValueError("not an MTRIDX1 sidecar")
-    if dtype != 0:
+    if dtype not in (DTYPE_F32, DTYPE_BF16):
         raise ValueError(f"unsupported sidecar dtype {dtype}")
-    return {"n": n, "d": d, "dtype": dtype, "source_size": size, "source_mtime_ns": mtime}
+    return {"n": n, "d": d, "dtype": dtype, "source_size": size, "source_mtime_ns": mtime,
+            "as_stored": bool(flags & FLAG_AS_STORED)}
 
 
-def open_sidecar(json_path: str):
-    """(memory-mapped (n, d) float32 matrix, page dicts) when a fresh sidecar
-    exists for json_path, else None."""
+def open_sidecar(json_path: str, with_header: bool = False):
+    """(memory-mapped (n, d) matrix, page dicts) when a fresh sidecar exists for
+    json_path, else None.  The matrix is float32, or uint16 bfloat16 bits for a
+    bf16 sidecar; with_header adds the parsed header as a third element."""
     mtr, pages = sidecar_paths(json_path)
     if not (os.path.exists(mtr) and os.path.exists(pages)):
         return None
@@ -94,12 +121,14 @@ def open_sidecar(json_path: str):
         st = os.stat(json_path)
         if (hdr["source_size"], hdr["source_mtime_ns"]) not in ((st.st_size, st.st_mtime_ns), (0, 0)):
             return None  # the JSON changed after the sidecar was written
-    expect = HEADER.size + hdr["n"] * hdr["d"] * 4
+    esize = 2 if hdr["dtype"] == DTYPE_BF16 else 4
+    expect = HEADER.size + hdr["n"] * hdr["d"] * esize
     if os.path.getsize(mtr) != expect:
         return None
-    matrix = np.memmap(mtr, dtype="<f4", mode="r", offset=HEADER.size, shape=(hdr["n"], hdr["d"]))
+    matrix = np.memmap(mtr, dtype="<u2" if esize == 2 else "<f4", mode="r", offset=HEADER.size,
+                       shape=(hdr["n"], hdr["d"]))
     with open(pages, "r", encoding="utf-8") as f:
         meta = json.load(f)
     if len(meta) != hdr["n"]:
         return None
-    return matrix, meta
+    return (matrix, meta, hdr) if with_header else (matrix, meta)

@@ -20,6 +20,7 @@ from __future__ import annotations
 import json
 import logging
 import os
+import threading
 from collections.abc import Sequence
 from pathlib import Path
 
@@ -28,25 +29,55 @@ import numpy as np
 from . import _native, index_format
 
 __all__ = ["PageIndex", "load_embeddings", "embed_queries", "embed_queries_device", "retrieve_top_index",
-           "get_surrounding_pages", "search", "configure"]
+           "get_surrounding_pages", "search", "configure", "configure_from_config", "invalidate"]
 
 _SETTINGS = {
     "device": int(os.environ.get("MEDTUTOR_RETRIEVAL_DEVICE", os.environ.get("LOCAL_RANK", "0")) or 0),
     "store_dtype": os.environ.get("MEDTUTOR_RETRIEVAL_DTYPE", "fp32"),
+    "top_k": 1,     # the reference keeps one page per keyword (np.argmax, local_rag.py:78)
+    "window": 1,    # ... and its two neighbours (get_surrounding_pages' default)
 }
 
 
-def configure(device: int | None = None, store_dtype: str | None = None) -> dict:
+def configure(device: int | None = None, store_dtype: str | None = None, top_k: int | None = None,
+              window: int | None = None) -> dict:
     """Sets the GPU and storage type ("fp32" or "bf16") used for indexes built
-    after this call.  Mirrors the optional config keys `local_retriever_devices`
-    / `local_index_dtype`; defaults keep fp32 on GPU 0."""
+    after this call, and the batched caller's hits per keyword / page window.
+    Defaults keep the reference's behaviour: fp32 on GPU 0, one hit, window 1."""
     if device is not None:
         _SETTINGS["device"] = int(device)
     if store_dtype is not None:
         if store_dtype not in _native.STORE_DTYPES:
             raise ValueError(f"store_dtype must be one of {sorted(_native.STORE_DTYPES)}")
         _SETTINGS["store_dtype"] = store_dtype
+    if top_k is not None:
+        if not 1 <= int(top_k) <= _native.MTR_MAX_K:
+            raise ValueError(f"top_k must be in [1, {_native.MTR_MAX_K}]")
+        _SETTINGS["top_k"] = int(top_k)
+    if window is not None:
+        if int(window) < 0:
+            raise ValueError("window must not be negative")
+        _SETTINGS["window"] = int(window)
     return dict(_SETTINGS)
+
+
+def configure_from_config(config: dict) -> dict:
+    """Reads the retriever's OPTIONAL keys from the pipeline's config dict -- the
+    one pipeline/async_main.py:190-195 takes `retrievers`, `local_index_path`,
+    `hf_embedding_model` and `embedding_model_device` from.  None of them exists
+    in the reference, and leaving them out keeps its behaviour:
+        local_index_dtype       "fp32" (default) | "bf16"
+        local_retriever_devices GPU ordinal, or a list of them (the first is used
+                                by this single-process retriever; the vLLM workers
+                                pin their own GPUs, async_main.py:39)
+        local_top_k             hits per keyword for the batched caller (default 1)
+        local_window            neighbouring pages on each side (default 1)
+    Unknown or absent keys are ignored; bad values raise ValueError."""
+    devices = config.get("local_retriever_devices")
+    if isinstance(devices, (list, tuple)):
+        devices = devices[0] if devices else None
+    return configure(device=devices, store_dtype=config.get("local_index_dtype"), top_k=config.get("local_top_k"),
+                     window=config.get("local_window"))
 
 
 class PageIndex(Sequence):
@@ -76,16 +107,29 @@ class PageIndex(Sequence):
 
     @classmethod
     def from_matrix(cls, matrix, pages_meta: list | None = None, device: int | None = None,
-                    store_dtype: str | None = None, normalize: bool = True):
-        matrix = _native.as_host_matrix(matrix, "matrix")
+                    store_dtype: str | None = None, normalize: bool = True, as_stored: bool = False):
+        """matrix: (n, d) floats, or uint16 bfloat16 bits (a bf16 index file).
+        as_stored: rows read back from a shard, not to be normalised again."""
+        matrix = _native.as_host_matrix(matrix, "rows")
         if pages_meta is None:
             pages_meta = [{"index": i, "text": ""} for i in range(matrix.shape[0])]
         if len(pages_meta) != matrix.shape[0]:
             raise ValueError("one page dict per matrix row is required")
         shard = _native.DeviceShard.from_host(
             matrix, store_dtype=store_dtype or _SETTINGS["store_dtype"], normalize=normalize,
-            device=_SETTINGS["device"] if device is None else device)
+            device=_SETTINGS["device"] if device is None else device, as_stored=as_stored)
         return cls(pages_meta, shard)
+
+    def save_sidecar(self, json_path: str, bind_to_source: bool = True):
+        """Writes the binary sidecar of json_path from this index's shard: a bf16
+        shard gives a bf16 file holding exactly its stored rows (half the bytes
+        of the fp32 form on disk and over PCIe; loading it reproduces the shard
+        bit for bit), an fp32 shard the fp32 form."""
+        if self._shard.info()["store_dtype"] == "bf16":
+            return index_format.write_sidecar(json_path, self._shard.read_rows_bf16(), self._pages,
+                                              bind_to_source=bind_to_source, as_stored=True)
+        return index_format.write_sidecar(json_path, self._shard.read_rows(), self._pages,
+                                          bind_to_source=bind_to_source, as_stored=True)
 
     # -- Sequence protocol ----------------------------------------------------
     def __len__(self):
@@ -122,26 +166,61 @@ class PageIndex(Sequence):
 
 
 # Plain page lists handed to retrieve_top_index are uploaded once and reused
-# while they keep their length; at most _UPLOADED_MAX such uploads are kept.
+# while they are the same list with the same vectors in it; at most
+# _UPLOADED_MAX such uploads are kept.
 _UPLOADED: dict = {}
 _UPLOADED_MAX = 2
+_UPLOADED_LOCK = threading.Lock()
+
+
+def _fingerprint(pages) -> tuple:
+    """Cheap identity of a page container's contents: its length and, for up to
+    64 evenly spaced pages, the identity of the vector object and two of its
+    values.  Replacing or editing a sampled vector, or changing the length,
+    changes it (the reference rebuilds its matrix on every call,
+    pipeline/utils/local_rag.py:76; an edit this sample misses needs invalidate())."""
+    n = len(pages)
+    if isinstance(pages, np.ndarray):
+        probe = pages[:: max(1, n // 64)]
+        return (n, pages.shape, float(probe.sum()))
+    marks = []
+    for i in range(0, n, max(1, n // 64)):
+        vec = pages[i]["embedding"] if isinstance(pages[i], dict) else pages[i]
+        marks.append((id(vec), len(vec), float(vec[0]) if len(vec) else 0.0, float(vec[-1]) if len(vec) else 0.0))
+    return (n, tuple(marks))
+
+
+def invalidate(page_embeddings=None) -> None:
+    """Forgets the uploaded copy of a plain page list (all of them when called
+    without one), for callers that edit vectors in place."""
+    with _UPLOADED_LOCK:
+        if page_embeddings is None:
+            _UPLOADED.clear()
+        else:
+            _UPLOADED.pop(id(page_embeddings), None)
 
 
 def _index_for(page_embeddings) -> PageIndex:
     if isinstance(page_embeddings, PageIndex):
         return page_embeddings
     key = id(page_embeddings)
-    hit = _UPLOADED.get(key)
-    # The entry keeps the container alive, so its id cannot be reused by another object.
-    if hit is not None and hit[0] is page_embeddings and hit[1] == len(page_embeddings):
-        return hit[2]
+    mark = _fingerprint(page_embeddings)
+    with _UPLOADED_LOCK:
+        hit = _UPLOADED.get(key)
+        # The entry keeps the container alive, so its id cannot be reused by another object.
+        if hit is not None and hit[0] is page_embeddings and hit[1] == mark:
+            return hit[2]
     if isinstance(page_embeddings, np.ndarray):
         index = PageIndex.from_matrix(page_embeddings)
     else:
         index = PageIndex.from_pages(list(page_embeddings))
-    while len(_UPLOADED) >= _UPLOADED_MAX:
-        _UPLOADED.pop(next(iter(_UPLOADED)))[2].close()
-    _UPLOADED[key] = (page_embeddings, len(page_embeddings), index)
+    with _UPLOADED_LOCK:
+        # Evicted entries are dropped, not closed: another thread may still be
+        # searching one, and its shard is freed when the last reference goes.
+        _UPLOADED.pop(key, None)
+        while len(_UPLOADED) >= _UPLOADED_MAX:
+            _UPLOADED.pop(next(iter(_UPLOADED)))
+        _UPLOADED[key] = (page_embeddings, mark, index)
     return index
 
 
@@ -154,10 +233,14 @@ def load_embeddings(path: str):
     if not path_obj.exists():
         logging.error(f"Embedding file not found: {path_obj}")
         return []
-    cached = index_format.open_sidecar(str(path_obj))
+    cached = index_format.open_sidecar(str(path_obj), with_header=True)
     if cached is not None:
-        matrix, meta = cached
-        index = PageIndex.from_matrix(matrix, meta)
+        matrix, meta, hdr = cached
+        # a bf16 file is a bf16 shard's stored rows: into a bf16 shard as they are; an fp32
+        # shard (local_index_dtype "fp32") takes the same values and normalises them in fp32
+        bf16_file = hdr["dtype"] == index_format.DTYPE_BF16
+        to_bf16 = _SETTINGS["store_dtype"] in ("bf16", "bfloat16")
+        index = PageIndex.from_matrix(matrix, meta, as_stored=hdr["as_stored"] and (to_bf16 or not bf16_file))
         logging.info(f"Loaded {len(index)} page embeddings (d={index.shard.d}) from the binary sidecar of {path_obj}")
         return index
     try:

@@ -96,3 +96,54 @@ def test_package_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f), encoding="utf-8").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+def test_sanitizer_build_of_the_abi_layer():
+    """make asan: the two host-logic files of the library compiled with
+    AddressSanitizer (host side only) and driven by csrc/abi_check.cpp through
+    every entry point's argument checks (plus a small search when a GPU is there)."""
+    import subprocess
+    csrc = os.path.join(ROOT, "medical-rag_amd", "csrc")
+    subprocess.run(["make", "-C", csrc, "asan", "-j4"], check=True, capture_output=True)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")   # the HIP runtime keeps its own allocations until exit
+    run = subprocess.run([os.path.join(ROOT, "medical-rag_amd", "abi_check_asan")], capture_output=True, text=True, env=env,
+                         timeout=300)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "abi_check: 0 failure(s)" in run.stdout
+    assert "AddressSanitizer" not in run.stderr
+
+
+def test_configure_from_config_reads_optional_keys():
+    from medical_rag_amd import local_rag as rag
+    before = rag.configure()
+    try:
+        # the reference's own config has none of the keys: nothing changes
+        assert rag.configure_from_config({"retrievers": ["local"], "local_index_path": "x.json"}) == before
+        got = rag.configure_from_config({"local_index_dtype": "bf16", "local_retriever_devices": [3, 4],
+                                         "local_top_k": 5, "local_window": 2})
+        assert (got["store_dtype"], got["device"], got["top_k"], got["window"]) == ("bf16", 3, 5, 2)
+        assert rag.configure_from_config({"local_retriever_devices": 1})["device"] == 1
+        with pytest.raises(ValueError):
+            rag.configure_from_config({"local_index_dtype": "int4"})
+        with pytest.raises(ValueError):
+            rag.configure_from_config({"local_top_k": 0})
+    finally:
+        rag.configure(**before)
+
+
+def test_uploaded_list_fingerprint_sees_edits():
+    from medical_rag_amd import local_rag as rag
+    pages = [{"index": i, "text": str(i), "embedding": [float(i), 1.0, 2.0]} for i in range(200)]
+    a = rag._fingerprint(pages)
+    assert rag._fingerprint(pages) == a
+    pages[0]["embedding"] = [9.0, 9.0, 9.0]              # vector replaced
+    b = rag._fingerprint(pages)
+    assert b != a
+    pages[0]["embedding"][0] = -1.0                       # vector edited in place
+    assert rag._fingerprint(pages) != b
+    pages.append({"index": 200, "text": "x", "embedding": [0.0, 0.0, 1.0]})
+    assert rag._fingerprint(pages)[0] == 201
+    m = np.zeros((50, 4), dtype=np.float32)
+    fm = rag._fingerprint(m)
+    m[0, 0] = 3.0
+    assert rag._fingerprint(m) != fm

@@ -769,6 +769,62 @@ def test_sidecar_load_matches_json_load(rag, tmp_path):
     assert rag.get_surrounding_pages(3, from_sidecar) == rag.get_surrounding_pages(3, from_json)
 
 
+def test_bf16_sidecar_reproduces_the_shard(rag, tmp_path):
+    """A bf16 index file written from a bf16 shard holds its stored rows; loading
+    it (no second normalisation) gives the same shard bit for bit, at half the
+    bytes of the fp32 file."""
+    import json
+    import os
+    from medical_rag_amd import index_format
+    rng = np.random.default_rng(43)
+    mat = (rng.standard_normal((700, 192)) * 3).astype(np.float32)
+    mat[5] = 0
+    pages = [{"index": i % 9, "text": f"p{i}", "embedding": r.tolist()} for i, r in enumerate(mat)]
+    path = tmp_path / "embedded_pages_hf_z.json"
+    path.write_text(json.dumps(pages))
+    queries = rng.standard_normal((40, 192)).astype(np.float32)
+    before = rag.configure()
+    try:
+        rag.configure(store_dtype="bf16")
+        from_json = rag.load_embeddings(str(path))
+        want = from_json.search(queries, k=7)
+        mtr, _ = from_json.save_sidecar(str(path))
+        hdr = index_format.read_header(mtr)
+        assert hdr["dtype"] == index_format.DTYPE_BF16 and hdr["as_stored"]
+        assert os.path.getsize(mtr) == index_format.HEADER.size + mat.size * 2
+        from_file = rag.load_embeddings(str(path))
+        assert (from_file.shard.read_rows() == from_json.shard.read_rows()).all()
+        got = from_file.search(queries, k=7)
+        assert (got[0] == want[0]).all() and (got[1] == want[1]).all()
+        assert list(from_file) == list(from_json)
+        # index_format.convert(..., "bf16") writes the same file
+        os.remove(mtr)
+        index_format.convert(str(path), store_dtype="bf16")
+        again = rag.load_embeddings(str(path))
+        assert (again.shard.read_rows() == from_json.shard.read_rows()).all()
+        # the bf16 file into an fp32 shard: the same values, normalised in fp32
+        rag.configure(store_dtype="fp32")
+        as_f32 = rag.load_embeddings(str(path))
+        assert as_f32.shard.info()["store_dtype"] == "fp32"
+        np.testing.assert_allclose(as_f32.shard.read_rows(), from_json.shard.read_rows(), atol=2e-3, rtol=0)
+    finally:
+        rag.configure(**before)
+
+
+def test_plain_list_edited_in_place_is_uploaded_again(rag):
+    rng = np.random.default_rng(12)
+    mat = rng.standard_normal((60, 16)).astype(np.float32)
+    pages = [{"index": i, "text": str(i), "embedding": r.tolist()} for i, r in enumerate(mat)]
+    q = mat[7] * 2.0
+    assert rag.retrieve_top_index(q, pages) == 7
+    pages[0]["embedding"] = (mat[7] * 3.0).tolist()      # page 0 now points the same way: lowest index wins
+    assert rag.retrieve_top_index(q, pages) == 0
+    pages[0]["embedding"][0] += 50.0                     # edited in place
+    assert rag.retrieve_top_index(q, pages) == 7
+    rag.invalidate(pages)
+    assert rag.retrieve_top_index(q, pages) == 7
+
+
 def test_batched_caller_matches_reference_loop(rag, golden):
     from medical_rag_amd import caller
     a, e = golden("g6_caller_glue")

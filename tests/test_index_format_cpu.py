@@ -65,3 +65,23 @@ def test_write_sidecar_without_source(tmp_path):
     assert got_meta == meta
     with pytest.raises(ValueError):
         fmt.write_sidecar(base, mat, meta[:2])
+
+
+def test_bf16_sidecar_round_trip(tmp_path):
+    """A uint16 matrix is stored as bfloat16 bits with the as-stored flag and comes back as it went in."""
+    import json
+    import numpy as np
+    from medical_rag_amd import index_format
+    rng = np.random.default_rng(5)
+    bits = (rng.standard_normal((37, 24)).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+    meta = [{"index": i, "text": f"p{i}"} for i in range(37)]
+    path = str(tmp_path / "embedded_pages_hf_y.json")
+    mtr, _ = index_format.write_sidecar(path, bits, meta, bind_to_source=False, as_stored=True)
+    hdr = index_format.read_header(mtr)
+    assert (hdr["n"], hdr["d"], hdr["dtype"], hdr["as_stored"]) == (37, 24, index_format.DTYPE_BF16, True)
+    matrix, got_meta, hdr2 = index_format.open_sidecar(path, with_header=True)
+    assert matrix.dtype == np.uint16 and (np.asarray(matrix) == bits).all() and got_meta == meta and hdr2 == hdr
+    assert os.path.getsize(mtr) == index_format.HEADER.size + bits.size * 2
+    # fp32 sidecars keep reading as before, flag clear
+    index_format.write_sidecar(path, bits.astype(np.float32), meta, bind_to_source=False)
+    assert index_format.read_header(mtr)["as_stored"] is False and index_format.open_sidecar(path)[0].dtype == np.float32
