@@ -186,6 +186,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--rows", type=int, default=None)
+    ap.add_argument("--dim", type=int, default=None)
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--k", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -228,6 +229,8 @@ def main():
     w = dict(WORKLOADS[args.workload])
     if args.rows:
         w["rows"] = args.rows
+    if args.dim:
+        w["dim"] = args.dim
     if args.batch:
         w["batch"] = args.batch
     if args.k:
@@ -324,7 +327,7 @@ def main():
         local_bytes = (hi - lo) * dim * esize  # algorithmic bytes of one scan launch on this rank
         achieved = local_bytes / (scan_avg_ms * 1e-3) / 1e9
         passes = n_launch / args.steps
-        default_shape = world == 1 and not (args.rows or args.batch or args.k)
+        default_shape = world == 1 and not (args.rows or args.batch or args.k or args.dim)
         traffic, traffic_file = pmc_traffic(args.workload, default_shape)
         # The library hands batches of >= 2 (bf16) / 3 (fp32) queries to the matrix-core
         # kernel when rows are a multiple of 128 bytes (>= 256) and k <= 256.

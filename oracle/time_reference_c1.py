@@ -5,7 +5,10 @@ container (needs /root/reference; never runs on the GPU box).
 C1: N = 4032 pages (the shipped OCR splits), d = 4096 (Qwen3-Embedding-8B), the
 34 unique keywords of the sample keyword file, synthetic unit-norm vectors
 serialised as pipeline/utils/embed.py:74-79 does (Python lists of floats).
-Writes profiles/r01_c1_reference_cpu.json.
+Environment: C1_DIM (4096; 3584 is the reference's fallback encoder,
+pipeline/utils/embed.py:91), C1_TAG (prefix of the output file, default r02);
+BLAS threads follow OMP_NUM_THREADS / OPENBLAS_NUM_THREADS as set by the caller
+and are recorded.  Writes profiles/<tag>_c1_reference_cpu_d<dim>[_t<threads>].json.
 """
 import json
 import os
@@ -43,13 +46,16 @@ def main():
     out = {
         "config": f"C1: N={n}, d={d}, {b} queries, top-1 (reference as written)",
         "host": f"{os.cpu_count()} vCPU build container, numpy {np.__version__}",
+        "blas_threads": os.environ.get("OMP_NUM_THREADS") or os.environ.get("OPENBLAS_NUM_THREADS") or "default (all cores)",
         "retrieve_top_index_ms_per_query": as_written * 1e3,
         "queries_per_s_as_written": 1.0 / as_written,
         "cosine_similarity_only_ms_per_query": scoring_only * 1e3,
         "queries_per_s_matrix_cached": 1.0 / scoring_only,
         "top1": tops,
     }
-    path = os.path.join(ROOT, "profiles", f"r01_c1_reference_cpu_d{d}.json")
+    threads = os.environ.get("OMP_NUM_THREADS") or os.environ.get("OPENBLAS_NUM_THREADS")
+    tag = os.environ.get("C1_TAG", "r02")
+    path = os.path.join(ROOT, "profiles", f"{tag}_c1_reference_cpu_d{d}" + (f"_t{threads}" if threads else "") + ".json")
     with open(path, "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps({k: v for k, v in out.items() if k != "top1"}, indent=1))
