@@ -65,6 +65,35 @@ class NativeLibraryError(RuntimeError):
     pass
 
 
+def _share_torch_hip_runtime():
+    """One process must not hold two HIP runtimes: the second one finds no GPU.
+    PyTorch-ROCm wheels bring their own libamdhip64.so (loaded by file name),
+    this library asks for the system's libamdhip64.so.7 (by soname).  Loaded
+    after torch, the soname resolves to torch's copy and all is well; loaded
+    BEFORE torch -- the reference's order: load_embeddings at
+    pipeline/async_main.py:190 runs before embed_queries imports torch at
+    pipeline/utils/local_rag.py:23 -- torch would bring a second runtime and
+    fail with "No HIP GPUs are available".  So when a torch wheel with a
+    bundled runtime is installed, that copy is mapped first (no torch import,
+    no GPU initialisation) and serves both.  MEDTUTOR_HIP_RUNTIME=system skips this."""
+    if os.environ.get("MEDTUTOR_HIP_RUNTIME", "").lower() == "system":
+        return None
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return None
+    if spec is None or not spec.origin:
+        return None
+    bundled = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if not os.path.exists(bundled):
+        return None
+    try:
+        return C.CDLL(bundled, mode=C.RTLD_GLOBAL)
+    except OSError:
+        return None
+
+
 def lib():
     """The loaded library; raises NativeLibraryError when it has not been built."""
     global _lib
@@ -75,6 +104,7 @@ def lib():
                     raise NativeLibraryError(
                         f"{LIB_PATH} is missing: build it with `make -C medical-rag_amd/csrc` "
                         "(or python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+                _share_torch_hip_runtime()
                 handle = C.CDLL(LIB_PATH)
                 for name, (res, args) in SIGNATURES.items():
                     fn = getattr(handle, name)

@@ -102,9 +102,13 @@ __device__ __forceinline__ void stage_tile(const char* base, long long row0, lon
                                            int k0_bytes, char* lds, int wave, int lane) {
     // ROWS rows x 128 bytes.  One wave instruction fills 8 rows; lane L writes
     // LDS position (row L/8, slot L%8) and fetches chunk (L%8) ^ (L/8) of it.
+    // Fewer 8-row pieces than waves (a 32-query tile under eight waves): the first
+    // ROWS / 8 waves take one piece each, the others none.
+    constexpr int PER_WAVE = ROWS >= 8 * WAVES ? ROWS / (8 * WAVES) : 1;
+    if (ROWS < 8 * WAVES && wave >= ROWS / 8) return;
 #pragma unroll
-    for (int i = 0; i < ROWS / (8 * WAVES); ++i) {
-        const int t = wave * (ROWS / (8 * WAVES)) + i;
+    for (int i = 0; i < PER_WAVE; ++i) {
+        const int t = wave * PER_WAVE + i;
         const int r = t * 8 + (lane >> 3);
         long long row = row0 + r;
         row = row < row_max ? row : row_max;
@@ -368,8 +372,9 @@ __device__ __forceinline__ void write_range_lists(int q0, int nq, int qt_base, i
 template <typename T, int CAP, int TNQ, bool MAX_ONLY, int ROW_AUX, int NS, int TM = kTileRows>
 __global__ __launch_bounds__(TM == 256 ? 512 : 256, TM == 256 ? 1 : 2) void score_topk_mfma_kernel(MfmaArgs a) {
     static_assert(NS == 2 || (NS == 3 && !MAX_ONLY), "the ring form exists for the full launch only");
-    static_assert(TM == 128 || (TM == 256 && (TNQ == 64 || TNQ == 128) && NS == 3), "the tall tile exists for 64 and 128 queries in the ring form");
-    static_assert(TNQ % (8 * (TM == 256 ? 8 : 4)) == 0, "every wave stages at least one 8-row piece of the query tile");
+    static_assert(TM == 128 || (TM == 256 && NS == 3), "the tall tile exists in the ring form only");
+    static_assert(TNQ % (8 * (TM == 256 ? 8 : 4)) == 0 || TNQ / 8 < (TM == 256 ? 8 : 4),
+                  "the query tile is staged in whole 8-row pieces: an equal number per wave, or one each by the first waves");
     constexpr int kThreads = TM == 256 ? 512 : 256;
     if (a.run_if && *a.run_if == 0) return;
     constexpr int TN = TNQ;
@@ -392,7 +397,7 @@ __global__ __launch_bounds__(TM == 256 ? 512 : 256, TM == 256 ? 1 : 2) void scor
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the counted waits branch on it
     const int row_off = (wave / WN) * (32 * MT);   // the wave's rows inside the tile
     const int q_off = (wave % WN) * (32 * NT);     // ... and its queries
 
@@ -440,7 +445,12 @@ __global__ __launch_bounds__(TM == 256 ? 512 : 256, TM == 256 ? 1 : 2) void scor
 
     const long long total_steps = my_tiles * ksteps;
     if constexpr (NS == 3) {
-        constexpr int LPS = (TM + TNQ) / (8 * WAVES);  // load instructions per wave and step
+        // Load instructions per wave and step: the row pieces, plus the wave's query pieces
+        // (one for the first TNQ / 8 waves only when the query tile has fewer pieces than waves).
+        constexpr int LPS_ROWS = TM / (8 * WAVES);
+        constexpr bool kUnevenQ = TNQ < 8 * WAVES;
+        constexpr int LPS = LPS_ROWS + (kUnevenQ ? 0 : TNQ / (8 * WAVES));
+        const bool extra_q = kUnevenQ && wave < TNQ / 8;
         long long ld_tile = tile_lo, ld_ptile = phys(tile_lo);
         int ld_ks = 0, ld_stage = 0;
         auto request_step = [&]() {
@@ -463,8 +473,9 @@ __global__ __launch_bounds__(TM == 256 ? 512 : 256, TM == 256 ? 1 : 2) void scor
         int ks = 0, cur = 0;
         for (long long s = 0; s < total_steps; ++s) {
             // step s has landed (this wave's share; the barrier extends it to all)
-            if (s + 1 < total_steps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (s + 1 >= total_steps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (extra_q) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS + 1) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
             barrier_keeping_loads();
             // every wave is past the MFMAs of step s - 1: its buffer takes step s + 2
             if (s + 2 < total_steps) request_step();
@@ -618,7 +629,7 @@ int plan_mfma(int dtype, int64_t n, int ld, int b, int k, int num_cus, int sampl
     // 0.375 ms; fp32 shards are bound by the fp32 matrix rate there and lose 1-2 %
     // to the ring's two workgroups per CU).
     // The 128-query tile has the ring only in its 256-row form (below).
-    const bool tall_shape = plan->tnq >= 64 && dtype == 2 && k <= 128;
+    const bool tall_shape = dtype == 2 && k <= 128;   // 256-row tiles (eight waves): bf16, every tile width
     plan->stages = (plan->stream_rows && dtype == 2 && (plan->tnq <= 64 || tall_shape)) ? 3 : 2;
     if (tn.mfma_stages) plan->stages = (!sampling && tn.mfma_stages == 3 && (plan->tnq <= 64 || tall_shape)) ? 3 : 2;
     // ... with 256-row tiles (eight waves) for the 64- and 128-query tiles (bf16, k <= 128).
@@ -723,6 +734,7 @@ hipError_t launch_score_mfma(const void* rows, int dtype, int64_t n, int ld, con
     }
     if (plan.tm == 256) {
         if (plan.stages != 3 || plan.cap != 512 || dtype != 2 || a.tile_max != nullptr) return hipErrorInvalidValue;
+        if (plan.tnq == 32) return launch(&score_topk_mfma_kernel<bf16_t, 512, 32, false, 2, 3, 256>);
         if (plan.tnq == 64) return launch(&score_topk_mfma_kernel<bf16_t, 512, 64, false, 2, 3, 256>);
         if (plan.tnq == 128) return launch(&score_topk_mfma_kernel<bf16_t, 512, 128, false, 2, 3, 256>);
         return hipErrorInvalidValue;

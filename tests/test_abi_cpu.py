@@ -147,3 +147,22 @@ def test_uploaded_list_fingerprint_sees_edits():
     fm = rag._fingerprint(m)
     m[0, 0] = 3.0
     assert rag._fingerprint(m) != fm
+
+
+def test_one_hip_runtime_whatever_the_import_order():
+    """The library loaded BEFORE torch (the reference's order: load_embeddings
+    runs before embed_queries imports torch) must leave the process with one
+    HIP runtime, or torch's later GPU initialisation finds no device."""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from medical_rag_amd import _native\n"
+        "_native.lib().mtr_version()\n"
+        "import torch\n"
+        "torch.zeros(1)\n"
+        "maps = sorted({l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l})\n"
+        "print(len(maps), maps)\n" % ROOT)
+    run = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stderr
+    assert run.stdout.startswith("1 "), run.stdout
