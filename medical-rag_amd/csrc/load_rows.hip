@@ -38,7 +38,7 @@ __device__ __forceinline__ double wave_sum_f64(double x) {
 template <typename SrcT, typename DstT>
 __global__ __launch_bounds__(256) void load_rows_kernel(const SrcT* __restrict__ src, long long n_rows, int d,
                                                          DstT* __restrict__ dst, int ld, int normalize,
-                                                         int* __restrict__ nonfinite_flag) {
+                                                         NonfiniteFlag nonfinite_flag) {
     const int lane = threadIdx.x & 63;
     const long long wave_id = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void load_rows_kernel(const SrcT* __restrict__
             }
         }
         if (__ballot(bad) != 0ull) {
-            if (lane == 0) atomicOr(nonfinite_flag, 1);
+            if (lane == 0) atomicMax(nonfinite_flag.word, nonfinite_flag.value);
         }
         double inv = 1.0;
         if (normalize) {
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void read_rows_kernel(const T* __restrict__ ro
 
 template <typename SrcT>
 hipError_t launch_src(const void* src, int64_t n_rows, int d, void* dst, int dst_dtype, int ld, int normalize,
-                      int* flag, hipStream_t stream) {
+                      NonfiniteFlag flag, hipStream_t stream) {
     long long blocks = (n_rows + 3) / 4;
     if (blocks > 8192) blocks = 8192;
     if (blocks < 1) blocks = 1;
@@ -134,7 +134,7 @@ hipError_t launch_src(const void* src, int64_t n_rows, int d, void* dst, int dst
 }  // namespace
 
 hipError_t launch_load_rows(const void* src, int src_dtype, int64_t n_rows, int d, void* dst, int dst_dtype, int ld,
-                            int normalize, int* nonfinite_flag, hipStream_t stream) {
+                            int normalize, NonfiniteFlag nonfinite_flag, hipStream_t stream) {
     if (n_rows <= 0) return hipSuccess;
     switch (src_dtype) {
         case 0: return launch_src<float>(src, n_rows, d, dst, dst_dtype, ld, normalize, nonfinite_flag, stream);

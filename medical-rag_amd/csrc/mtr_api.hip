@@ -155,7 +155,9 @@ struct mtr_index {
     int64_t row_offset = 0;
     int num_cus = 256;
     void* rows = nullptr;
-    int* flag = nullptr;  // device word set by the loader on NaN/inf
+    int* flag = nullptr;  // device word that kernels raise to the call's epoch on NaN/inf (mtr::NonfiniteFlag)
+    int epoch = 0;        // last value handed out; the word never needs clearing
+    int device_epoch = 0; // ... and the one of the last search enqueued without waiting
     hipStream_t stream = nullptr;
     std::mutex mu;
     DevBuf scratch[kScratchSlots];  // grown on demand, kept between searches
@@ -292,7 +294,7 @@ int next_event_pair(mtr_index* ix, hipEvent_t* e0, hipEvent_t* e1) {
 // launch, then the merge of the per-range lists.
 template <typename S>
 int enqueue_mfma(mtr_index* ix, S& sc, const mtr::MfmaPlan& plan, const void* dev_queries, int q_dtype, int b, int k,
-                 int metric, long long* dev_out_idx, float* dev_out_score, hipStream_t stream) {
+                 int metric, mtr::NonfiniteFlag nf, long long* dev_out_idx, float* dev_out_score, hipStream_t stream) {
     int rc;
     // Large shards get a sampling launch first: every stride-th row tile is
     // scored and only each query's best score per tile is kept.  The k-th
@@ -372,7 +374,7 @@ int enqueue_mfma(mtr_index* ix, S& sc, const mtr::MfmaPlan& plan, const void* de
         HIP_TRY(hipMemsetAsync(qbuf + (size_t)b * q_row_bytes, 0, (size_t)(q_rows - b) * q_row_bytes, stream));
     }
     HIP_TRY(mtr::launch_load_rows(dev_queries, q_dtype, b, ix->d, qbuf, ix->dtype, ix->ld,
-                                  metric == MTR_COSINE ? 1 : 0, ix->flag, stream));
+                                  metric == MTR_COSINE ? 1 : 0, nf, stream));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool profiling = ix->profiling && sc.may_profile();
     if (profiling) {
@@ -421,13 +423,21 @@ int enqueue_mfma(mtr_index* ix, S& sc, const mtr::MfmaPlan& plan, const void* de
 // q_dtype on the shard's device.
 template <typename S>
 int enqueue_search(mtr_index* ix, S& sc, const void* dev_queries, int q_dtype, int b, int k, int metric,
-                   long long* dev_out_idx, float* dev_out_score, hipStream_t stream) {
+                   long long* dev_out_idx, float* dev_out_score, hipStream_t stream, int* epoch_out = nullptr) {
+    // this search's value of the non-finite word (see mtr::NonfiniteFlag)
+    if (ix->epoch == 0x7fffffff) {   // once in two billion searches: start over
+        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(hipMemset(ix->flag, 0, 4));
+        ix->epoch = 0;
+    }
+    const mtr::NonfiniteFlag nf{ix->flag, ++ix->epoch};
+    if (epoch_out) *epoch_out = nf.value;
     if (metric == MTR_COSINE && !ix->normalized)
         return fail(MTR_ERR_INVALID, "cosine search needs a shard built with normalize=1");
     if (b >= mfma_min_batch(ix->dtype)) {
         mtr::MfmaPlan mplan;
         if (mtr::plan_mfma(ix->dtype, ix->n, ix->ld, b, k, ix->num_cus, 0, &mplan) == 0)
-            return enqueue_mfma(ix, sc, mplan, dev_queries, q_dtype, b, k, metric, dev_out_idx, dev_out_score, stream);
+            return enqueue_mfma(ix, sc, mplan, dev_queries, q_dtype, b, k, metric, nf, dev_out_idx, dev_out_score, stream);
     }
     mtr::ScanPlan plan;
     if (mtr::plan_scan(ix->dtype, ix->n, ix->d, ix->ld, b, k, ix->num_cus, &plan) != 0)
@@ -452,7 +462,7 @@ int enqueue_search(mtr_index* ix, S& sc, const void* dev_queries, int q_dtype, i
         if (!raw) {
             if (nb < plan.qb) HIP_TRY(hipMemsetAsync(q_f32, 0, (size_t)plan.qb * plan.qstride * 4, stream));
             HIP_TRY(mtr::launch_load_rows(qsrc, q_dtype, nb, ix->d, q_f32, MTR_F32, plan.qstride,
-                                          metric == MTR_COSINE ? 1 : 0, ix->flag, stream));
+                                          metric == MTR_COSINE ? 1 : 0, nf, stream));
         }
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (profiling) {
@@ -461,7 +471,7 @@ int enqueue_search(mtr_index* ix, S& sc, const void* dev_queries, int q_dtype, i
         }
         HIP_TRY(mtr::launch_scan_topk(ix->rows, ix->dtype, ix->n, ix->ld, ix->d, q_f32,
                                       raw ? reinterpret_cast<const float*>(qsrc) : nullptr, nb,
-                                      metric == MTR_COSINE ? 1 : 0, ix->flag, k, plan, cand_s, cand_i, stream));
+                                      metric == MTR_COSINE ? 1 : 0, nf, k, plan, cand_s, cand_i, stream));
         if (profiling) HIP_TRY(hipEventRecord(e1, stream));
         // the scan's per-workgroup lists are sorted best first
         HIP_TRY(mtr::launch_merge_sorted_lists(cand_s, cand_i, plan.grid, (long long)k, (long long)plan.grid * k, k, nb, k,
@@ -546,7 +556,8 @@ namespace {
 
 // Host rows -> shard through page-locked staging: the host copy of chunk i + 1
 // into its pinned buffer runs while chunk i crosses PCIe and is converted.
-int upload_host_rows(mtr_index* ix, int64_t row_start, const char* rows, int64_t n_rows, int src_dtype, int normalize) {
+int upload_host_rows(mtr_index* ix, int64_t row_start, const char* rows, int64_t n_rows, int src_dtype, int normalize,
+                     mtr::NonfiniteFlag nf) {
     int rc;
     const size_t esize = dtype_size(ix->dtype);
     const size_t src_row = (size_t)ix->d * dtype_size(src_dtype);
@@ -574,8 +585,8 @@ int upload_host_rows(mtr_index* ix, int64_t row_start, const char* rows, int64_t
         memcpy(ix->pinned[i], rows + (size_t)r0 * src_row, (size_t)nr * src_row);
         HIP_TRY(hipMemcpyAsync(ix->stage[i].p, ix->pinned[i], (size_t)nr * src_row, hipMemcpyHostToDevice, ix->stream));
         char* dst = static_cast<char*>(ix->rows) + (size_t)(row_start + r0) * ix->ld * esize;
-        HIP_TRY(mtr::launch_load_rows(ix->stage[i].p, src_dtype, nr, ix->d, dst, ix->dtype, ix->ld, normalize,
-                                      ix->flag, ix->stream));
+        HIP_TRY(mtr::launch_load_rows(ix->stage[i].p, src_dtype, nr, ix->d, dst, ix->dtype, ix->ld, normalize, nf,
+                                      ix->stream));
         HIP_TRY(hipEventRecord(ix->stage_done[i], ix->stream));
     }
     return MTR_OK;
@@ -598,22 +609,21 @@ int mtr_index_load_rows(mtr_index_t* ix, int64_t row_start, const void* rows, in
     std::lock_guard<std::mutex> lock(ix->mu);
     DeviceGuard guard(ix->device);
     if ((rc = begin_use(ix, ix->stream)) != MTR_OK) return rc;
-    HIP_TRY(hipMemsetAsync(ix->flag, 0, 4, ix->stream));
+    const mtr::NonfiniteFlag nf{ix->flag, ++ix->epoch};
     if (n_rows == 0) {
         // nothing to convert
     } else if (rows_on_device) {
         char* dst = static_cast<char*>(ix->rows) + (size_t)row_start * ix->ld * dtype_size(ix->dtype);
-        HIP_TRY(mtr::launch_load_rows(rows, src_dtype, n_rows, ix->d, dst, ix->dtype, ix->ld, normalize, ix->flag,
-                                      ix->stream));
-    } else if ((rc = upload_host_rows(ix, row_start, static_cast<const char*>(rows), n_rows, src_dtype, normalize)) != MTR_OK) {
+        HIP_TRY(mtr::launch_load_rows(rows, src_dtype, n_rows, ix->d, dst, ix->dtype, ix->ld, normalize, nf, ix->stream));
+    } else if ((rc = upload_host_rows(ix, row_start, static_cast<const char*>(rows), n_rows, src_dtype, normalize, nf)) != MTR_OK) {
         (void)hipStreamSynchronize(ix->stream);
         return rc;
     }
     int flag = 0;
     HIP_TRY(hipMemcpyAsync(&flag, ix->flag, 4, hipMemcpyDeviceToHost, ix->stream));
-    if ((rc = end_use(ix, ix->stream)) != MTR_OK) return rc;
     HIP_TRY(hipStreamSynchronize(ix->stream));
-    if (flag) return fail(MTR_ERR_NONFINITE, "Input contains NaN or infinity.");
+    ix->used = false;   // everything enqueued on the handle has finished: the next call has nothing to wait for
+    if (flag == nf.value) return fail(MTR_ERR_NONFINITE, "Input contains NaN or infinity.");
     return MTR_OK;
 }
 
@@ -647,15 +657,15 @@ int mtr_index_search(mtr_index_t* ix, const void* queries, int32_t q_dtype, int3
     }
     if ((rc = ix->out_i.reserve((size_t)b * k * 8)) != MTR_OK) return rc;
     if ((rc = ix->out_s.reserve((size_t)b * k * 4)) != MTR_OK) return rc;
-    HIP_TRY(hipMemsetAsync(ix->flag, 0, 4, ix->stream));
     Scratch sc;
     sc.ix = ix;
+    int epoch = 0;
     rc = enqueue_search(ix, sc, dq, q_dtype, b, k, metric, static_cast<long long*>(ix->out_i.p),
-                        static_cast<float*>(ix->out_s.p), ix->stream);
+                        static_cast<float*>(ix->out_s.p), ix->stream, &epoch);
     if (rc != MTR_OK) {
         std::string keep = g_err;
-        (void)end_use(ix, ix->stream);
         (void)hipStreamSynchronize(ix->stream);
+        ix->used = false;
         g_err = keep;
         return rc;
     }
@@ -663,9 +673,11 @@ int mtr_index_search(mtr_index_t* ix, const void* queries, int32_t q_dtype, int3
     HIP_TRY(hipMemcpyAsync(out_idx, ix->out_i.p, (size_t)b * k * 8, hipMemcpyDeviceToHost, ix->stream));
     HIP_TRY(hipMemcpyAsync(out_score, ix->out_s.p, (size_t)b * k * 4, hipMemcpyDeviceToHost, ix->stream));
     HIP_TRY(hipMemcpyAsync(&flag, ix->flag, 4, hipMemcpyDeviceToHost, ix->stream));
-    if ((rc = end_use(ix, ix->stream)) != MTR_OK) return rc;
+    // The call waits for its own work, so it leaves nothing for a later call on
+    // another stream to wait for: no event needs recording.
     HIP_TRY(hipStreamSynchronize(ix->stream));
-    if (flag) return fail(MTR_ERR_NONFINITE, "Input contains NaN or infinity.");
+    ix->used = false;
+    if (flag == epoch) return fail(MTR_ERR_NONFINITE, "Input contains NaN or infinity.");
     return MTR_OK;
 }
 
@@ -677,11 +689,10 @@ int mtr_index_search_device(mtr_index_t* ix, const void* dev_queries, int32_t q_
     DeviceGuard guard(ix->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if ((rc = begin_use(ix, s)) != MTR_OK) return rc;
-    HIP_TRY(hipMemsetAsync(ix->flag, 0, 4, s));
     Scratch sc;
     sc.ix = ix;
     rc = enqueue_search(ix, sc, dev_queries, q_dtype, b, k, metric, reinterpret_cast<long long*>(dev_out_idx),
-                        dev_out_score, s);
+                        dev_out_score, s, &ix->device_epoch);
     std::string keep = g_err;
     const int rc2 = end_use(ix, s);
     if (rc != MTR_OK) g_err = keep;
@@ -700,7 +711,7 @@ int mtr_index_search_device_noalloc(mtr_index_t* ix, const void* dev_queries, in
     StaticScratch sc;
     sc.ix = ix;
     return enqueue_search(ix, sc, dev_queries, q_dtype, b, k, metric, reinterpret_cast<long long*>(dev_out_idx),
-                          dev_out_score, static_cast<hipStream_t>(stream));
+                          dev_out_score, static_cast<hipStream_t>(stream), &ix->device_epoch);
 }
 
 int mtr_index_nonfinite(mtr_index_t* ix, int32_t* nonfinite) {
@@ -712,7 +723,7 @@ int mtr_index_nonfinite(mtr_index_t* ix, int32_t* nonfinite) {
     if (ix->used) HIP_TRY(hipEventSynchronize(ix->last_use));
     int flag = 0;
     HIP_TRY(hipMemcpy(&flag, ix->flag, 4, hipMemcpyDeviceToHost));
-    *nonfinite = flag ? 1 : 0;
+    *nonfinite = (ix->device_epoch > 0 && flag == ix->device_epoch) ? 1 : 0;
     return MTR_OK;
 }
 
@@ -774,8 +785,8 @@ int mtr_index_read_rows(mtr_index_t* ix, int64_t row_start, int64_t n_rows, floa
     const char* src = static_cast<const char*>(ix->rows) + (size_t)row_start * ix->ld * dtype_size(ix->dtype);
     HIP_TRY(mtr::launch_read_rows(src, ix->dtype, n_rows, ix->d, ix->ld, static_cast<float*>(ix->stage[0].p), ix->stream));
     HIP_TRY(hipMemcpyAsync(host_out, ix->stage[0].p, bytes, hipMemcpyDeviceToHost, ix->stream));
-    if ((rc = end_use(ix, ix->stream)) != MTR_OK) return rc;
     HIP_TRY(hipStreamSynchronize(ix->stream));
+    ix->used = false;
     return MTR_OK;
 }
 
@@ -845,7 +856,7 @@ int mtr_index_read_ceiling(mtr_index_t* ix, int32_t reps, float* avg_ms) {
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    if ((rc = end_use(ix, ix->stream)) != MTR_OK) return rc;
+    ix->used = false;   // every launch above was waited for
     *avg_ms = (float)(sum / reps);
     return MTR_OK;
 }

@@ -67,11 +67,20 @@ Tuning& tuning();
 
 // ---- host-callable launchers (defined in the .hip files) -------------------
 
+// Where a kernel reports NaN/inf in its input: it raises *word to `value`
+// (atomic max).  The caller hands out ever increasing values, one per call, and
+// afterwards asks whether the word equals its value: the word never needs
+// clearing between calls, which saves a launch per search.
+struct NonfiniteFlag {
+    int* word;
+    int value;
+};
+
 // Row loader: finiteness check, optional L2 normalisation (float64 norm; norms
 // below 10*DBL_EPSILON count as 1), cast to the storage type, zero padding of
 // columns [d, ld).  src_dtype / dst_dtype use the MTR_F32/F64/BF16 codes.
 hipError_t launch_load_rows(const void* src, int src_dtype, int64_t n_rows, int d, void* dst,
-                            int dst_dtype, int ld, int normalize, int* nonfinite_flag,
+                            int dst_dtype, int ld, int normalize, NonfiniteFlag nonfinite_flag,
                             hipStream_t stream);
 
 // Copies stored rows back as fp32 (n_rows x d).
@@ -97,7 +106,7 @@ int plan_scan(int dtype, int64_t n, int d, int ld, int b, int k, int num_cus, Sc
 // q_raw != NULL) can be given: every workgroup then normalises (if asked) and
 // pads them itself and reports NaN/inf through nonfinite_flag.
 hipError_t launch_scan_topk(const void* rows, int dtype, int64_t n, int ld, int d, const float* q,
-                            const float* q_raw, int nb, int normalize, int* nonfinite_flag, int k,
+                            const float* q_raw, int nb, int normalize, NonfiniteFlag nonfinite_flag, int k,
                             const ScanPlan& plan, float* cand_s, int* cand_i, hipStream_t stream);
 
 // Candidate merge: for each of b queries, the best k_out of n_lists * k_in

@@ -77,7 +77,7 @@ struct ScanArgs {
     int d;
     int nb;
     int normalize;
-    int* nonfinite_flag;  // set when a raw query holds NaN/inf
+    NonfiniteFlag nonfinite_flag;  // raised when a raw query holds NaN/inf
     int qstride;   // floats per padded query = nit * 16 * EPC
     int k;
     float* cand_s; // [QB][gridDim.x][k]
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(waves_per_group(QB) * 64) void scan_topk_kernel(Sca
                     }
                 }
             }
-            if (__ballot(bad) != 0ull && lane == 0 && blockIdx.x == 0) atomicOr(a.nonfinite_flag, 1);
+            if (__ballot(bad) != 0ull && lane == 0 && blockIdx.x == 0) atomicMax(a.nonfinite_flag.word, a.nonfinite_flag.value);
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) {
                 int lo = __double2loint(ss), hi = __double2hiint(ss);
@@ -436,7 +436,7 @@ hipError_t launch_scan_read_only(const void* rows, int dtype, int64_t n, int ld,
 }
 
 hipError_t launch_scan_topk(const void* rows, int dtype, int64_t n, int ld, int d, const float* q,
-                            const float* q_raw, int nb, int normalize, int* nonfinite_flag, int k,
+                            const float* q_raw, int nb, int normalize, NonfiniteFlag nonfinite_flag, int k,
                             const ScanPlan& plan, float* cand_s, int* cand_i, hipStream_t stream) {
     const int esize = dtype == 0 ? 4 : 2;
     ScanArgs a;
