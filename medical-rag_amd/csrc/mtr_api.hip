@@ -249,14 +249,16 @@ int end_use(mtr_index* ix, hipStream_t stream) {
 }
 
 // Smallest batch that goes to the matrix-core kernel; below it the HBM-bound
-// scan handles the batch in passes of up to four queries.  Measured hand-over
-// (1M rows): bf16 x 1024 -- scan 0.33 ms for one query, 0.46 ms for two,
-// matrix cores (32-query tiles) 0.40 ms for two to eight; fp32 x 768 -- scan
-// 0.50 ms for two, 0.80 ms for four, matrix cores (fp32 MFMA) 0.61 ms for three.
+// scan handles the batch in passes of up to four (bf16) or eight (fp32) queries.
+// Measured hand-over (1M rows, ms per search): bf16 x 1024 -- scan 0.315 for one
+// query, 0.349 / 0.360 / 0.367 for two / three / four, matrix cores (32-query
+// tiles) 0.349 for two to sixteen; fp32 x 768 -- scan 0.46 / 0.49 / 0.51 / 0.51 for
+// one to four and 0.55-0.57 for five to eight, matrix cores (fp32 MFMA) 0.61 for
+// three, 0.58-0.59 for four to eight, 0.60 for twelve (two scan passes: 1.1).
 int mfma_min_batch(int dtype) {
     const int forced = mtr::tuning().mfma_min_batch;
     if (forced > 0) return forced;
-    return dtype == MTR_BF16 ? 2 : 3;
+    return dtype == MTR_BF16 ? 2 : 9;
 }
 
 // Every how many row tiles one goes into the sampling launch (< 2: no sample).
@@ -901,7 +903,7 @@ const TuningField kTuningFields[] = {
     {"mfma_sample_stride", &mtr::Tuning::mfma_sample_stride}, {"mfma_stream_rows", &mtr::Tuning::mfma_stream_rows},
     {"mfma_stages", &mtr::Tuning::mfma_stages},           {"mfma_tile_rows", &mtr::Tuning::mfma_tile_rows},
     {"wide_min_batch", &mtr::Tuning::wide_min_batch},     {"scan_wg_per_cu", &mtr::Tuning::scan_wg_per_cu},
-    {"scan_nontemporal", &mtr::Tuning::scan_nontemporal}, {"pool_sliced", &mtr::Tuning::pool_sliced},
+    {"scan_nontemporal", &mtr::Tuning::scan_nontemporal}, {"scan_max_qb", &mtr::Tuning::scan_max_qb}, {"pool_sliced", &mtr::Tuning::pool_sliced},
 #ifdef MTR_TIMING_SWITCHES
     {"timing_mfma", &mtr::Tuning::timing_mfma},           {"timing_wide", &mtr::Tuning::timing_wide},
 #endif

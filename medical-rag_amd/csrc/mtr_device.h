@@ -57,6 +57,7 @@ struct Tuning {
     int mfma_tile_rows = 0;       // rows per tile 128 / 256 (0: by form)
     int wide_min_batch = 129;     // smallest batch for the 256 x 256-tile kernel
     int scan_wg_per_cu = 0;       // scan workgroups per CU (0: one for a single query, occupancy otherwise)
+    int scan_max_qb = 0;          // most queries per scan pass 1 / 2 / 4 / 8 (0: four)
     int scan_nontemporal = -1;    // -1: streaming row loads on shards beyond the caches; 0 / 1
     int pool_sliced = -1;         // pooling kernel form: -1 by shape (two kernels from 256 tokens); 0 one kernel; 1 two kernels
     int timing_mfma = 0;          // MTR_TIMING_SWITCHES builds only: drop candidates / skip loads or MFMAs (wrong results)

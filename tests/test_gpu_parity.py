@@ -383,7 +383,7 @@ def test_full_size_properties(native):
 
 
 MFMA_SHAPES = [
-    # n, d, b, k   (rows that are a multiple of 128 bytes and b >= 2 (bf16) / 3 (fp32) take the matrix-core kernel;
+    # n, d, b, k   (rows that are a multiple of 128 bytes and b >= 2 (bf16) / 9 (fp32) take the matrix-core kernel;
     #               b <= 32 / <= 64 / more select its 32- / 64- / 128-query tiles, k <= 32 the small buffers)
     (5000, 512, 5, 10),
     (3000, 320, 31, 40),
