@@ -65,8 +65,19 @@ def gather_candidates(idx, score, group=None):
 
 
 def exchange(mine: CandidateBlock, everyone: CandidateBlock, group=None):
+    """All-gather of one candidate block per rank through torch.distributed:
+    RCCL for device tensors under backend "nccl"; gloo for CPU tensors, and for
+    device tensors staged through the host (ranks that have no RCCL
+    communicator between them, e.g. several ranks sharing one GPU in a test:
+    the copies synchronise the stream)."""
+    import torch
     import torch.distributed as dist
     if dist.get_backend(group) == "gloo":
+        if everyone.buf.is_cuda:
+            host = torch.empty(everyone.buf.shape, dtype=everyone.buf.dtype)
+            dist.all_gather([host[r] for r in range(everyone.n_blocks)], mine.buf[0].cpu(), group=group)
+            everyone.buf.copy_(host)
+            return
         parts = [everyone.buf[r] for r in range(everyone.n_blocks)]
         dist.all_gather(parts, mine.buf[0], group=group)
     else:

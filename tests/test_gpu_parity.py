@@ -747,6 +747,58 @@ def test_library_communicator_on_one_rank(native):
     comm.close()
 
 
+def _two_rank_worker(rank, world, port, ret):
+    import os
+    import sys
+    import torch
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from medical_rag_amd import _native
+        from medical_rag_amd.sharded import ShardedIndex, shard_bounds
+        from oracle import local_rag_oracle as orc
+        torch.cuda.set_device(0)
+        rng = np.random.default_rng(99)
+        n, d = 30011, 256
+        corpus = rng.integers(-3, 4, size=(n, d)).astype(np.float32)      # integer data: exact scores, ties everywhere
+        corpus[n - 1] = corpus[0]                                          # a tie between the first and the last rank
+        lo, hi = shard_bounds(n, world, rank)
+        shard = _native.DeviceShard.from_host(corpus[lo:hi], store_dtype="bf16", normalize=False, row_offset=lo)
+        index = ShardedIndex(shard)
+        ok = index.world_size == world
+        for b, k in ((1, 10), (40, 7), (1, 10), (3, 33)):
+            queries = rng.integers(-3, 4, size=(b, d)).astype(np.float32)
+            q = torch.from_numpy(queries).cuda()
+            gi, gs = index.search_device(q, k=k, metric="ip")
+            torch.cuda.synchronize()
+            wi, ws = orc.search(queries, corpus, k, metric="ip")
+            ok = ok and bool((gi.cpu().numpy() == wi).all()) and bool((gs.cpu().numpy() == ws.astype(np.float32)).all())
+        ret[rank] = bool(ok)
+        shard.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_processes_search_their_shards_and_merge():
+    """The row-sharded search with MORE THAN ONE RANK on hardware: two processes, each
+    with its half of the corpus in HBM (both on this box's one GPU, so the exchange goes
+    through gloo with host staging: RCCL refuses two ranks on one device), local search
+    and final merge in the HIP kernels.  Every rank must end with the unsharded
+    oracle's answer, bit for bit on integer data."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_two_rank_worker, args=(2, port, ret), nprocs=2, join=True)
+        assert dict(ret) == {0: True, 1: True}
+
+
 def test_merge_reads_packed_gathered_buffer(native):
     """The exchange buffer layout of the multi-GPU path: every rank's ids and
     scores in one block, merged through strided views without copies."""
