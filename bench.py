@@ -192,6 +192,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-exchange", action="store_true",
                     help="initialise the process group and run the all-gather + merge even with one rank")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="all ranks share GPU 0 and exchange over gloo (RCCL refuses two ranks on one device): a "
+                         "rehearsal of the multi-rank code path on a one-GPU box, not a measurement")
     ap.add_argument("--torch-exchange", action="store_true",
                     help="all-gather through torch.distributed instead of the library's RCCL communicator")
     ap.add_argument("--pipeline-depth", type=int, default=-1,
@@ -213,6 +216,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit(f"rank {rank} wants GPU {local_rank}, but only {torch.cuda.device_count()} are visible")
     torch.cuda.set_device(local_rank)
@@ -220,11 +225,14 @@ def main():
     if world > 1 or args.force_exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        # torch.distributed carries the RCCL unique id, the barriers and the max over ranks of the
-        # elapsed time; the searches' all-gather runs on the library's own communicator.
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
-        if not args.torch_exchange:
-            comm = native.Comm.from_process_group(local_rank)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            # torch.distributed carries the RCCL unique id, the barriers and the max over ranks of the
+            # elapsed time; the searches' all-gather runs on the library's own communicator.
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+            if not args.torch_exchange:
+                comm = native.Comm.from_process_group(local_rank)
 
     w = dict(WORKLOADS[args.workload])
     if args.rows:
@@ -299,7 +307,7 @@ def main():
     samples = sorted(shard.scan_samples())
     shard.profile(False)
     if world > 1:
-        t = torch.tensor([elapsed], device=f"cuda:{local_rank}", dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cpu" if args.rehearse_on_one_gpu else f"cuda:{local_rank}", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -382,6 +390,7 @@ def main():
                        "rows_per_gpu": hi - lo,
                        "parallelism": f"row-shard x{world}" + (" + RCCL all-gather + k-way merge" if world > 1 else ""),
                        "exchange": ("library RCCL communicator (mtr_sharded_search_device)" if comm is not None
+                                    else "REHEARSAL: all ranks on one GPU, gloo" if args.rehearse_on_one_gpu and exchanging
                                     else "torch.distributed" if exchanging else None),
                        "exchange_pipeline_depth": depth},
             "roofline": roof,
