@@ -158,8 +158,8 @@ int exchange_and_merge(mtr_comm* c, mtr_comm::Slot* s, int b, int k_in, int k_ou
 // A block of padding: ids -1, scores -inf (what a rank without rows contributes).
 int fill_padding(mtr_comm::Slot* s, int b, int k, hipStream_t stream) {
     const size_t cells = (size_t)b * k;
-    HIP_TRY(hipMemsetAsync(s->send, 0xFF, cells * 8, stream));
-    HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(s->send + cells), 0xFF800000u, cells, stream));
+    HIP_TRY(mtr::launch_fill_u32(s->send, 0xFFFFFFFFu, cells * 2, stream));
+    HIP_TRY(mtr::launch_fill_u32(s->send + cells, 0xFF800000u, cells, stream));
     return MTR_OK;
 }
 

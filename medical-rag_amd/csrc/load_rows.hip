@@ -112,6 +112,11 @@ __global__ __launch_bounds__(256) void read_rows_kernel(const T* __restrict__ ro
     }
 }
 
+__global__ __launch_bounds__(256) void fill_u32_kernel(unsigned int* __restrict__ dst, unsigned int value, size_t n_words) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = value;
+}
+
 template <typename SrcT>
 hipError_t launch_src(const void* src, int64_t n_rows, int d, void* dst, int dst_dtype, int ld, int normalize,
                       NonfiniteFlag flag, hipStream_t stream) {
@@ -142,6 +147,15 @@ hipError_t launch_load_rows(const void* src, int src_dtype, int64_t n_rows, int 
         case 2: return launch_src<bf16_t>(src, n_rows, d, dst, dst_dtype, ld, normalize, nonfinite_flag, stream);
         default: return hipErrorInvalidValue;
     }
+}
+
+hipError_t launch_fill_u32(void* dst, unsigned int value, size_t n_words, hipStream_t stream) {
+    if (n_words == 0) return hipSuccess;
+    size_t blocks = (n_words + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, static_cast<unsigned int*>(dst), value,
+                       n_words);
+    return hipGetLastError();
 }
 
 hipError_t launch_read_rows(const void* rows, int dtype, int64_t n_rows, int d, int ld, float* dst,

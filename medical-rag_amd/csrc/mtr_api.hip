@@ -359,21 +359,21 @@ int enqueue_mfma(mtr_index* ix, S& sc, const mtr::MfmaPlan& plan, const void* de
     if (tile_max_bytes && (rc = sc.need(kTileMax, tile_max_bytes)) != MTR_OK) return rc;
     if ((rc = sc.ready()) != MTR_OK) return rc;
     // A sampling launch's floor kernel sets every real query's floor; otherwise they start from zero.
-    if (stride < 2) HIP_TRY(hipMemsetAsync(sc.p[kMfmaFloor], 0, (size_t)floor_words * 4, stream));
+    if (stride < 2) HIP_TRY(mtr::launch_fill_u32(sc.p[kMfmaFloor], 0u, (size_t)floor_words, stream));
     // Query rows past b must be zero.
     char* qbuf = static_cast<char*>(sc.p[kQTiles]);
     if (sc.keeps_query_tiles()) {
         if (sc.p[kQTiles] != q_old) ix->q_init_rows = ix->q_data_rows = 0;
         if (q_rows > ix->q_init_rows) {
-            HIP_TRY(hipMemsetAsync(qbuf + (size_t)ix->q_init_rows * q_row_bytes, 0,
-                                   (size_t)(q_rows - ix->q_init_rows) * q_row_bytes, stream));
+            HIP_TRY(mtr::launch_fill_u32(qbuf + (size_t)ix->q_init_rows * q_row_bytes, 0u,
+                                         (size_t)(q_rows - ix->q_init_rows) * q_row_bytes / 4, stream));
             ix->q_init_rows = q_rows;
         }
         if (ix->q_data_rows > b)
-            HIP_TRY(hipMemsetAsync(qbuf + (size_t)b * q_row_bytes, 0, (size_t)(ix->q_data_rows - b) * q_row_bytes, stream));
+            HIP_TRY(mtr::launch_fill_u32(qbuf + (size_t)b * q_row_bytes, 0u, (size_t)(ix->q_data_rows - b) * q_row_bytes / 4, stream));
         ix->q_data_rows = b;
     } else if (q_rows > b) {
-        HIP_TRY(hipMemsetAsync(qbuf + (size_t)b * q_row_bytes, 0, (size_t)(q_rows - b) * q_row_bytes, stream));
+        HIP_TRY(mtr::launch_fill_u32(qbuf + (size_t)b * q_row_bytes, 0u, (size_t)(q_rows - b) * q_row_bytes / 4, stream));
     }
     HIP_TRY(mtr::launch_load_rows(dev_queries, q_dtype, b, ix->d, qbuf, ix->dtype, ix->ld,
                                   metric == MTR_COSINE ? 1 : 0, nf, stream));
@@ -399,9 +399,9 @@ int enqueue_mfma(mtr_index* ix, S& sc, const mtr::MfmaPlan& plan, const void* de
         unsigned long long* keys = static_cast<unsigned long long*>(sc.p[kWideKeys]);
         unsigned int* tile_max = static_cast<unsigned int*>(sc.p[kTileMax]);
         overflow = reinterpret_cast<int*>(counts + wide.count_words);
-        HIP_TRY(hipMemsetAsync(overflow, 0, 4, stream));
+        HIP_TRY(mtr::launch_fill_u32(overflow, 0u, 1, stream));
         // the sampling form raises tile_max with atomic maxima: every word starts at zero (below any score)
-        HIP_TRY(hipMemsetAsync(tile_max, 0, (size_t)wide.n_qtiles * 256 * wide_samp.n_tiles * 4, stream));
+        HIP_TRY(mtr::launch_fill_u32(tile_max, 0u, (size_t)wide.n_qtiles * 256 * wide_samp.n_tiles, stream));
         HIP_TRY(mtr::launch_score_wide(ix->rows, ix->n, ix->ld, qbuf, b, wide_samp, nullptr, nullptr, nullptr, wstride,
                                        tile_max, stream));
         HIP_TRY(mtr::launch_floor_from_tile_max(tile_max, (int)wide_samp.n_tiles, b, k, floors, stream));
@@ -462,7 +462,7 @@ int enqueue_search(mtr_index* ix, S& sc, const void* dev_queries, int q_dtype, i
         const char* qsrc = static_cast<const char*>(dev_queries) + (size_t)b0 * ix->d * qsize;
         const bool raw = q_dtype == MTR_F32;
         if (!raw) {
-            if (nb < plan.qb) HIP_TRY(hipMemsetAsync(q_f32, 0, (size_t)plan.qb * plan.qstride * 4, stream));
+            if (nb < plan.qb) HIP_TRY(mtr::launch_fill_u32(q_f32, 0u, (size_t)plan.qb * plan.qstride, stream));
             HIP_TRY(mtr::launch_load_rows(qsrc, q_dtype, nb, ix->d, q_f32, MTR_F32, plan.qstride,
                                           metric == MTR_COSINE ? 1 : 0, nf, stream));
         }

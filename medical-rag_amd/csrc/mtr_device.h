@@ -84,6 +84,13 @@ hipError_t launch_load_rows(const void* src, int src_dtype, int64_t n_rows, int 
                             int dst_dtype, int ld, int normalize, NonfiniteFlag nonfinite_flag,
                             hipStream_t stream);
 
+// dst[0 .. n_words) = value (32-bit words), as a kernel.  Used instead of
+// hipMemsetAsync wherever a search clears scratch: memset nodes captured into a
+// HIP graph replay with a garbage fill value on this runtime from the second
+// replay on (measured: 128 bytes "zeroed" to +inf bit patterns), and searches
+// are meant to be capturable.
+hipError_t launch_fill_u32(void* dst, unsigned int value, size_t n_words, hipStream_t stream);
+
 // Copies stored rows back as fp32 (n_rows x d).
 hipError_t launch_read_rows(const void* rows, int dtype, int64_t n_rows, int d, int ld, float* dst,
                             hipStream_t stream);

@@ -111,3 +111,33 @@ def test_noalloc_rejects_what_does_not_fit(native):
     (want_i, want_s), (got_i, got_s) = _both(shard, q1, 10)
     assert torch.equal(got_i, want_i) and torch.equal(got_s, want_s)
     shard.close()
+
+
+def test_noalloc_search_can_be_captured_in_a_graph(native):
+    """The callers this entry point is for: a search captured once under stream
+    capture and replayed, with new queries copied into the captured input."""
+    import torch
+    gen = torch.Generator(device="cuda").manual_seed(13)
+    n, d, k = 120_000, 256, 10
+    shard = native.DeviceShard.alloc(n, d, store_dtype="bf16")
+    shard.load_device(0, torch.randn((n, d), generator=gen, device="cuda"))
+    for b in (1, 6):
+        q = torch.randn((b, d), generator=gen, device="cuda")
+        out = (torch.empty((b, k), dtype=torch.int64, device="cuda"), torch.empty((b, k), dtype=torch.float32, device="cuda"))
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            shard.search_device_noalloc(q, out, k=k)      # once outside capture: kernel attributes get set here
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            shard.search_device_noalloc(q, out, k=k, stream=torch.cuda.current_stream().cuda_stream)
+        for _ in range(4):          # (the second replay is the first that can see what a replay left behind)
+            q.copy_(torch.randn((b, d), generator=gen, device="cuda"))
+            out[0].fill_(-9)
+            graph.replay()
+            torch.cuda.synchronize()
+            want_i, want_s = shard.search_device(q, k=k)
+            torch.cuda.synchronize()
+            assert torch.equal(out[0], want_i) and torch.equal(out[1], want_s)
+        del graph
+    shard.close()
