@@ -174,6 +174,7 @@ def launch_ranks(n_gpus):
     for rank in range(n_gpus):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n_gpus),
                    LOCAL_WORLD_SIZE=str(n_gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs between processes on this driver
         children.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     codes = [child.wait() for child in children]
     return max((abs(c) for c in codes), default=0)
