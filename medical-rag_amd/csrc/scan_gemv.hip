@@ -100,6 +100,40 @@ __global__ __launch_bounds__(waves_per_group(QB) * 64) void scan_topk_kernel(Sca
     const int lane = tid & 63;
     const int wave = tid >> 6;
 
+    const long long ngroups = (a.n + kGroupRows - 1) / kGroupRows;
+    const long long gstride = (long long)gridDim.x * kWaves;
+    const int col = lane & (kLanesPerRow - 1);   // this lane's chunk within a sweep
+    const int lrow = lane >> 4;                  // ... and its row within a quad
+    const long long g_first = (long long)blockIdx.x * kWaves + wave;
+
+    // The rows do not depend on the queries: the wave's first batch of row loads
+    // goes out before the query set-up below (two dependent rounds of global
+    // loads and a barrier, about 5 us during which the memory system would idle).
+    auto request_batch = [&](long long g, int s0, u32x4 (&raw)[kSweepsPerBatch][kQuads]) {
+        const char* rp[kQuads];
+#pragma unroll
+        for (int qd = 0; qd < kQuads; ++qd) {
+            long long row = g * kGroupRows + qd * 4 + lrow;
+            row = row < a.n ? row : a.n - 1;
+            rp[qd] = a.rows + row * a.row_bytes;
+        }
+#pragma unroll
+        for (int u = 0; u < kSweepsPerBatch; ++u) {
+            if (s0 + u < a.nit) {   // wave-uniform
+                const int chunk = (s0 + u) * kLanesPerRow + col;
+                // Chunks past the row's data read chunk 0 instead (always in
+                // bounds); their query values are zero.
+                const int chunk_c = chunk < a.nchunks ? chunk : 0;
+#pragma unroll
+                for (int qd = 0; qd < kQuads; ++qd)
+                    raw[u][qd] = load_chunk<NT>(reinterpret_cast<const u32x4*>(rp[qd] + (size_t)chunk_c * 16));
+            }
+        }
+    };
+    u32x4 raw[kSweepsPerBatch][kQuads];
+    bool requested = g_first < ngroups;   // wave-uniform: raw holds (or awaits) batch 0 of group g_first
+    if (requested) request_batch(g_first, 0, raw);
+
     if (a.q_raw) {
         // fp32 queries straight from the caller: float64 norm (zero norm counts as
         // 1, as for the rows), scale, zero-pad -- redone by every workgroup, which
@@ -173,24 +207,13 @@ __global__ __launch_bounds__(waves_per_group(QB) * 64) void scan_topk_kernel(Sca
 #pragma unroll
     for (int b = 0; b < QB; ++b) tk[b].init(list_s + (wave * QB + b) * a.k, list_i + (wave * QB + b) * a.k, a.k);
 
-    const long long ngroups = (a.n + kGroupRows - 1) / kGroupRows;
-    const long long gstride = (long long)gridDim.x * kWaves;
-    const int col = lane & (kLanesPerRow - 1);   // this lane's chunk within a sweep
-    const int lrow = lane >> 4;                  // ... and its row within a quad
     // The lane that reports the total of (quad, query): col = quad * QB + query.
     const int my_quad = col / QB;
     const int my_b = col % QB;
     const bool owner = col < kQuads * QB;
 
-    for (long long g = (long long)blockIdx.x * kWaves + wave; g < ngroups; g += gstride) {
+    for (long long g = g_first; g < ngroups; g += gstride) {
         const long long row0 = g * kGroupRows;
-        const char* rp[kQuads];
-#pragma unroll
-        for (int qd = 0; qd < kQuads; ++qd) {
-            long long row = row0 + qd * 4 + lrow;
-            row = row < a.n ? row : a.n - 1;
-            rp[qd] = a.rows + row * a.row_bytes;
-        }
         float acc[kQuads][QB];
 #pragma unroll
         for (int qd = 0; qd < kQuads; ++qd)
@@ -198,19 +221,8 @@ __global__ __launch_bounds__(waves_per_group(QB) * 64) void scan_topk_kernel(Sca
             for (int b = 0; b < QB; ++b) acc[qd][b] = 0.f;
 
         for (int s0 = 0; s0 < a.nit; s0 += kSweepsPerBatch) {
-            u32x4 raw[kSweepsPerBatch][kQuads];
-#pragma unroll
-            for (int u = 0; u < kSweepsPerBatch; ++u) {
-                if (s0 + u < a.nit) {   // wave-uniform
-                    const int chunk = (s0 + u) * kLanesPerRow + col;
-                    // Chunks past the row's data read chunk 0 instead (always in
-                    // bounds); their query values are zero.
-                    const int chunk_c = chunk < a.nchunks ? chunk : 0;
-#pragma unroll
-                    for (int qd = 0; qd < kQuads; ++qd)
-                        raw[u][qd] = load_chunk<NT>(reinterpret_cast<const u32x4*>(rp[qd] + (size_t)chunk_c * 16));
-                }
-            }
+            if (!requested) request_batch(g, s0, raw);
+            requested = false;
 #pragma unroll
             for (int u = 0; u < kSweepsPerBatch; ++u) {
                 if (s0 + u < a.nit) {
