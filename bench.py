@@ -207,6 +207,13 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args.gpus))   # nothing in this process has touched a GPU
 
+    # Only the JSON line may reach stdout: RCCL prints a version banner there when a
+    # communicator is created.  Everything else this process (and the libraries it loads)
+    # writes to file descriptor 1 goes to stderr; the line itself goes to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from medical_rag_amd import _native as native
@@ -400,7 +407,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(dim, k, rows)
-        print(json.dumps(res), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(res) + "\n").encode())
     shard.close()
     if comm is not None:
         comm.close()
