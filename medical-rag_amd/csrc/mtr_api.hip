@@ -902,7 +902,8 @@ const TuningField kTuningFields[] = {
     {"mfma_per_cu", &mtr::Tuning::mfma_per_cu},           {"mfma_cap", &mtr::Tuning::mfma_cap},
     {"mfma_sample_stride", &mtr::Tuning::mfma_sample_stride}, {"mfma_stream_rows", &mtr::Tuning::mfma_stream_rows},
     {"mfma_stages", &mtr::Tuning::mfma_stages},           {"mfma_tile_rows", &mtr::Tuning::mfma_tile_rows},
-    {"wide_min_batch", &mtr::Tuning::wide_min_batch},     {"scan_wg_per_cu", &mtr::Tuning::scan_wg_per_cu},
+    {"wide_min_batch", &mtr::Tuning::wide_min_batch},     {"wide_qgroup", &mtr::Tuning::wide_qgroup},
+        {"scan_wg_per_cu", &mtr::Tuning::scan_wg_per_cu},
     {"scan_nontemporal", &mtr::Tuning::scan_nontemporal}, {"scan_max_qb", &mtr::Tuning::scan_max_qb}, {"pool_sliced", &mtr::Tuning::pool_sliced},
 #ifdef MTR_TIMING_SWITCHES
     {"timing_mfma", &mtr::Tuning::timing_mfma},           {"timing_wide", &mtr::Tuning::timing_wide},

@@ -56,6 +56,7 @@ struct Tuning {
     int mfma_stages = 0;          // LDS stage buffers 2 / 3 (0: by form)
     int mfma_tile_rows = 0;       // rows per tile 128 / 256 (0: by form)
     int wide_min_batch = 129;     // smallest batch for the 256 x 256-tile kernel
+    int wide_qgroup = 0;          // its query tiles per row list on one XCD (0: four)
     int scan_wg_per_cu = 0;       // scan workgroups per CU (0: one for a single query, occupancy otherwise)
     int scan_max_qb = 0;          // most queries per scan pass 1 / 2 / 4 / 8 (0: four)
     int scan_nontemporal = -1;    // -1: streaming row loads on shards beyond the caches; 0 / 1

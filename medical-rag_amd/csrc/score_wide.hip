@@ -97,6 +97,8 @@ struct WideArgs {
     const char* queries;      // [n_qtiles*256][ld] bf16, zero rows past b
     int b;
     int n_lists;              // row lists (workgroups per query tile)
+    int n_qtiles;
+    int qgroup;               // query tiles that share a row list on one XCD (see the kernel)
     long long n_tiles;        // tiles this launch covers (numbered 0.. in its own order)
     int tile_stride;          // tile t of the launch is tile t * tile_stride of the matrix
     unsigned int* tile_max;   // sampling form: [n_qtiles*256][n_tiles] best score per (query, tile), zeroed by the caller
@@ -229,8 +231,18 @@ __global__ __launch_bounds__(kWideThreads, 2) void score_filter_wide_kernel(Wide
     const int wm = wave >> 2, wn = wave & 3;
     // XCD-aware, bijective workgroup remap: ids that land on one XCD become consecutive.
     const int nwg = gridDim.x, xcd = blockIdx.x % 8, per = nwg / 8, rem = nwg % 8;
-    const int wgid = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + blockIdx.x / 8;
-    const int qt = wgid / a.n_lists, list = wgid % a.n_lists;
+    const int sched = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + blockIdx.x / 8;
+    // Which (query tile, row list) pair the workgroup takes.  Pairs are numbered in blocks of
+    // qgroup query tiles: inside a block the query tile runs fastest, so the workgroups of one
+    // XCD (consecutive numbers) share each row list between qgroup query tiles -- a row tile
+    // that one of them has brought into the XCD's L2 is a hit for the others -- while their
+    // qgroup query tiles (512 KB each) stay resident in that L2 together.
+    const int qblock = sched / (a.qgroup * a.n_lists);           // (the last block may hold fewer query tiles)
+    const int qfirst = qblock * a.qgroup;
+    const int qhere = a.n_qtiles - qfirst < a.qgroup ? a.n_qtiles - qfirst : a.qgroup;
+    const int inner = sched - qblock * a.qgroup * a.n_lists;
+    const int list = inner / qhere, qt = qfirst + inner % qhere;
+    const int wgid = qt * a.n_lists + list;                      // its number in the key lists and counts
     long long my_tiles = a.n_tiles > list ? (a.n_tiles - list + a.n_lists - 1) / a.n_lists : 0;
     long long tile_step = a.n_lists, tile_first = list;
     if (MTR_TIMING(a) & 2) {  // contiguous ranges
@@ -457,6 +469,9 @@ hipError_t launch_score_wide(const void* rows, int64_t n, int ld, const void* qu
     a.queries = static_cast<const char*>(queries);
     a.b = b;
     a.n_lists = plan.n_lists;
+    a.n_qtiles = plan.n_qtiles;
+    a.qgroup = tuning().wide_qgroup > 0 ? tuning().wide_qgroup : 4;
+    if (a.qgroup > plan.n_qtiles) a.qgroup = plan.n_qtiles;
     a.n_tiles = plan.n_tiles;
     a.tile_stride = tile_stride < 1 ? 1 : tile_stride;
     a.tile_max = tile_max;
