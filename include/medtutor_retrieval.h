@@ -36,6 +36,7 @@ extern "C" {
 
 typedef struct mtr_index mtr_index_t;
 typedef struct mtr_comm mtr_comm_t;
+typedef struct mtr_json_index mtr_json_index_t;
 
 enum {
     MTR_OK = 0,
@@ -185,6 +186,27 @@ int mtr_comm_exchange_merge_device(mtr_comm_t* comm, const int64_t* dev_local_id
  * pipeline/utils/embed.py:68-72; the encoder forward stays in PyTorch. */
 int mtr_pool_normalize(const void* dev_hidden, int32_t dtype, const int64_t* dev_mask, int32_t b,
                        int32_t t, int32_t d, float* dev_out, int32_t device_id, void* stream);
+
+/* Reader of the reference's index file, host side only (no GPU): one JSON
+ * list of page objects, each with an "embedding" array of d numbers
+ * (written at pipeline/utils/embed.py:74-79,110-113).  Takes over the json.load
+ * of pipeline/utils/local_rag.py:96-98 for the vectors, which never become
+ * Python lists: mtr_json_index_scan walks `text` (len bytes of UTF-8, which
+ * must stay mapped until mtr_json_index_free) and finds every page's array;
+ * mtr_json_index_info gives the page count, d and the byte length of the
+ * "rest" -- the same text with each of those arrays replaced by null, for the
+ * caller's own JSON parser to turn into the page dicts; mtr_json_index_read
+ * converts the arrays into `matrix` (n_pages x d, MTR_F64 or MTR_F32, split
+ * over `threads` host threads) and copies the rest into `rest` (rest_len
+ * bytes, no terminator; NULL to skip).  Numbers follow Python's json module
+ * (JSON plus NaN, Infinity, -Infinity) with correct rounding, so an MTR_F64
+ * matrix equals numpy.array(json.load(...)) value for value.  A file that is
+ * anything else than such a list (or has rows of different lengths) is
+ * declined with MTR_ERR_INVALID, by either call: use a general parser then. */
+int mtr_json_index_scan(const char* text, int64_t len, mtr_json_index_t** out);
+int mtr_json_index_info(const mtr_json_index_t* parsed, int64_t* n_pages, int32_t* d, int64_t* rest_len);
+int mtr_json_index_read(const mtr_json_index_t* parsed, void* matrix, int32_t dtype, char* rest, int32_t threads);
+void mtr_json_index_free(mtr_json_index_t* parsed);
 
 /* Shape and storage of a shard. Any out pointer may be NULL. */
 int mtr_index_info(const mtr_index_t* index, int64_t* n, int32_t* d, int32_t* store_dtype,

@@ -52,6 +52,10 @@ SIGNATURES = {
     "mtr_tuning_set": (_i32, [C.c_char_p, _i32]),
     "mtr_tuning_get": (_i32, [C.c_char_p, C.POINTER(_i32)]),
     "mtr_index_read_ceiling": (_i32, [_vp, _i32, C.POINTER(C.c_float)]),
+    "mtr_json_index_scan": (_i32, [_vp, _i64, _pp]),
+    "mtr_json_index_info": (_i32, [_vp, C.POINTER(_i64), C.POINTER(_i32), C.POINTER(_i64)]),
+    "mtr_json_index_read": (_i32, [_vp, _vp, _i32, _vp, _i32]),
+    "mtr_json_index_free": (None, [_vp]),
     "mtr_index_destroy": (None, [_vp]),
     "mtr_last_error": (C.c_char_p, []),
     "mtr_version": (C.c_char_p, []),
@@ -159,6 +163,45 @@ class options:
         for name, value in self._old.items():
             set_option(name, value)
         return False
+
+
+def read_index_json(path: str, dtype=np.float64, threads: int | None = None):
+    """The reference's index file (pipeline/utils/embed.py:110-113) read by the
+    library's own reader: (matrix (n, d) of `dtype` float64/float32, the rest of
+    the file as UTF-8 bytes with every "embedding" array replaced by null).  The
+    vectors never become Python lists.  None when the reader declines the file
+    (anything but a list of objects with one flat numeric "embedding" each, all
+    of one length): the caller then parses it with the json module and gets that
+    module's behaviour."""
+    import mmap
+    code = np_dtype_code(np.empty(0, dtype=dtype))
+    if code not in (MTR_F32, MTR_F64):
+        raise TypeError("matrix dtype must be float32 or float64")
+    if threads is None:
+        threads = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count() or 1))
+    L = lib()
+    with open(path, "rb") as f:
+        if os.fstat(f.fileno()).st_size == 0:
+            return None
+        with mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ) as view:
+            text = np.frombuffer(view, dtype=np.uint8)
+            handle = _vp()
+            try:
+                if L.mtr_json_index_scan(text.ctypes.data, text.size, C.byref(handle)) != MTR_OK:
+                    return None
+                n, d, rest_len = _i64(), _i32(), _i64()
+                check(L.mtr_json_index_info(handle, C.byref(n), C.byref(d), C.byref(rest_len)))
+                matrix = np.empty((n.value, d.value), dtype=dtype)
+                rest = np.empty(rest_len.value, dtype=np.uint8)
+                rc = L.mtr_json_index_read(handle, matrix.ctypes.data if matrix.size else None, code,
+                                           rest.ctypes.data if rest.size else None, int(threads))
+                if rc != MTR_OK:
+                    return None
+                return matrix, rest.tobytes()
+            finally:
+                if handle:
+                    L.mtr_json_index_free(handle)
+                del text    # the mapping cannot close while an array still views it
 
 
 def np_dtype_code(a: np.ndarray) -> int:

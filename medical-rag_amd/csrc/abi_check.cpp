@@ -5,6 +5,7 @@
 // error code and a message, never with a crash or a leak.
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -19,8 +20,55 @@ static int failures = 0;
         }                                                                  \
     } while (0)
 
+// The index-file reader works on mapped text that ends without a terminator:
+// every prefix of a sample, and the sample with each byte damaged in turn, goes
+// through it in a heap block of exactly that size, so that a read past the end
+// is a sanitizer report.
+static void json_reader_checks() {
+    const char* sample =
+        " [ {\"index\": 1, \"text\": \"a \\\" ] } \\\\\", \"embedding\": [1, -2.5e-3, 12345678901234567890.125, NaN, -Infinity],"
+        " \"more\": {\"embedding\": [\"x\"], \"l\": [1, [2]]}},\n {\"embedding\":[0,0.1,1E5,Infinity,-0], \"index\": 2} ] \n";
+    const size_t full = strlen(sample);
+    mtr_json_index_t* js = nullptr;
+    EXPECT(mtr_json_index_scan(nullptr, 0, &js) == MTR_ERR_INVALID && js == nullptr);
+    EXPECT(mtr_json_index_scan(sample, (int64_t)full, nullptr) == MTR_ERR_INVALID);
+    EXPECT(mtr_json_index_info(nullptr, nullptr, nullptr, nullptr) == MTR_ERR_INVALID);
+    EXPECT(mtr_json_index_read(nullptr, nullptr, MTR_F64, nullptr, 1) == MTR_ERR_INVALID);
+    mtr_json_index_free(nullptr);
+    int accepted = 0;
+    for (int damage = -1; damage < (int)full; ++damage) {
+        for (size_t len = damage < 0 ? 0 : full; len <= full; ++len) {
+            char* text = static_cast<char*>(malloc(len ? len : 1));
+            memcpy(text, sample, len);
+            if (damage >= 0) text[damage] = "]\"\\,9e-"[damage % 7];
+            if (mtr_json_index_scan(text, (int64_t)len, &js) == MTR_OK) {
+                int64_t n = 0, rest_len = 0;
+                int32_t d = 0;
+                EXPECT(mtr_json_index_info(js, &n, &d, &rest_len) == MTR_OK);
+                std::vector<double> matrix((size_t)n * d + 1);
+                std::vector<char> rest((size_t)rest_len + 1);
+                EXPECT(mtr_json_index_read(js, matrix.data(), 9, rest.data(), 2) == MTR_ERR_INVALID);
+                if (mtr_json_index_read(js, matrix.data(), MTR_F64, rest.data(), 2) == MTR_OK && damage < 0) {
+                    ++accepted;
+                    EXPECT(len == full || len == full - 1 || len == full - 2);   // only the trailing blanks may go
+                    EXPECT(n == 2 && d == 5 && matrix[1] == -2.5e-3 && matrix[2] == 12345678901234567890.125 &&
+                           matrix[3] != matrix[3] && matrix[7] == 1e5 && matrix[8] > 1e308);
+                    std::vector<float> as_f32((size_t)n * d);
+                    EXPECT(mtr_json_index_read(js, as_f32.data(), MTR_F32, nullptr, 64) == MTR_OK && as_f32[6] == 0.1f);
+                }
+                mtr_json_index_free(js);
+            } else {
+                EXPECT(js == nullptr && strlen(mtr_last_error()) > 0);
+            }
+            free(text);
+        }
+    }
+    EXPECT(accepted == 3);
+}
+
 int main() {
     printf("%s\n", mtr_version());
+    json_reader_checks();
     mtr_index_t* ix = nullptr;
     EXPECT(mtr_index_alloc(0, 8, MTR_F32, 1, 0, 0, &ix) == MTR_ERR_INVALID && ix == nullptr);
     EXPECT(strlen(mtr_last_error()) > 0);

@@ -244,14 +244,22 @@ def load_embeddings(path: str):
         logging.info(f"Loaded {len(index)} page embeddings (d={index.shard.d}) from the binary sidecar of {path_obj}")
         return index
     try:
-        with open(path_obj, "r", encoding="utf-8") as f:
-            pages = json.load(f)
+        fast = index_format.read_json_index(str(path_obj))
+        if fast is None:        # not the plain list of pages: let json.load say what it is
+            with open(path_obj, "r", encoding="utf-8") as f:
+                pages = json.load(f)
     except json.JSONDecodeError:
         logging.error(f"Error decoding JSON from embedding file: {path_obj}")
         return []
-    if not pages:
-        return pages
-    index = PageIndex.from_pages(pages)
+    if fast is not None:
+        matrix, meta = fast
+        if not meta:
+            return []
+        index = PageIndex.from_matrix(matrix, meta)
+    else:
+        if not pages:
+            return pages
+        index = PageIndex.from_pages(pages)
     logging.info(f"Loaded {len(index)} page embeddings (d={index.shard.d}) into HBM on GPU {index.shard.info()['device']}")
     return index
 
