@@ -230,6 +230,7 @@ def main():
         raise SystemExit(f"rank {rank} wants GPU {local_rank}, but only {torch.cuda.device_count()} are visible")
     torch.cuda.set_device(local_rank)
     comm = None
+    comm_note = None
     if world > 1 or args.force_exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
@@ -240,7 +241,19 @@ def main():
             # elapsed time; the searches' all-gather runs on the library's own communicator.
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
             if not args.torch_exchange:
-                comm = native.Comm.from_process_group(local_rank)
+                # Either every rank exchanges through the library's communicator or none does.
+                try:
+                    comm = native.Comm.from_process_group(local_rank)
+                except Exception as exc:
+                    comm_note = f"{type(exc).__name__}: {exc}"
+                    print(f"[bench] rank {rank}: no library communicator ({comm_note})", file=sys.stderr, flush=True)
+                agreed = torch.tensor([1 if comm is not None else 0], device=f"cuda:{local_rank}", dtype=torch.int32)
+                dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+                if int(agreed.item()) == 0:
+                    if comm is not None:
+                        comm.close()
+                        comm = None
+                    comm_note = comm_note or "another rank could not create it"
 
     w = dict(WORKLOADS[args.workload])
     if args.rows:
@@ -399,7 +412,8 @@ def main():
                        "parallelism": f"row-shard x{world}" + (" + RCCL all-gather + k-way merge" if world > 1 else ""),
                        "exchange": ("library RCCL communicator (mtr_sharded_search_device)" if comm is not None
                                     else "REHEARSAL: all ranks on one GPU, gloo" if args.rehearse_on_one_gpu and exchanging
-                                    else "torch.distributed" if exchanging else None),
+                                    else "torch.distributed" + (f" (library communicator unavailable: {comm_note})" if comm_note else "")
+                                    if exchanging else None),
                        "exchange_pipeline_depth": depth},
             "roofline": roof,
             "needles_found": bool(needle_ok),

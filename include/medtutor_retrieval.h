@@ -127,7 +127,8 @@ int mtr_index_search_device_noalloc(mtr_index_t* index, const void* dev_queries,
 /* Whether the queries of the last mtr_index_search_device call on the handle
  * held a NaN or infinity (*nonfinite = 1; its results are then meaningless, and
  * the reference's scorer raises ValueError: pipeline/utils/local_rag.py:77).
- * Waits for that search to finish. */
+ * Waits for that search to finish.  After mtr_index_search_device_noalloc,
+ * which records no event, the caller synchronises with its stream first. */
 int mtr_index_nonfinite(mtr_index_t* index, int32_t* nonfinite);
 
 /* k-way merge of per-shard candidate lists on GPU device_id: inputs are
@@ -240,8 +241,8 @@ void mtr_index_destroy(mtr_index_t* index);
  * kernel forms of large shards onto small ones) and timing sweeps; not needed
  * for normal use.  Names: mfma_min_batch, mfma_tnq, mfma_per_cu, mfma_cap,
  * mfma_sample_stride, mfma_stream_rows, mfma_stages, mfma_tile_rows,
- * wide_min_batch, scan_wg_per_cu, scan_nontemporal, pool_sliced.  Each starts from the
- * environment variable MTR_<NAME> if set.  Unknown name: MTR_ERR_INVALID.
+ * wide_min_batch, wide_qgroup, scan_wg_per_cu, scan_nontemporal, scan_max_qb,
+ * pool_sliced.  Each starts from the environment variable MTR_<NAME> if set.  Unknown name: MTR_ERR_INVALID.
  * No counterpart in the reference. */
 int mtr_tuning_set(const char* name, int32_t value);
 int mtr_tuning_get(const char* name, int32_t* value);

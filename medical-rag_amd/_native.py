@@ -465,8 +465,15 @@ class Comm:
         which only carries rank 0's id to the others."""
         import torch.distributed as dist
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-        box = [cls.unique_id() if rank == 0 else None]
+        box = [None]
+        if rank == 0:
+            try:
+                box[0] = cls.unique_id()
+            except Exception as exc:        # carried to the others, so that every rank fails instead of waiting
+                box[0] = f"{type(exc).__name__}: {exc}"
         dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        if not isinstance(box[0], (bytes, bytearray)):
+            raise RuntimeError(f"rank 0 could not make a communicator id: {box[0]}")
         return cls.create(box[0], rank, world, device)
 
     def sharded_search(self, shard, queries, out, k=10, metric="cosine", stream=None):

@@ -842,22 +842,27 @@ int mtr_index_read_ceiling(mtr_index_t* ix, int32_t reps, float* avg_ms) {
     if (mtr::plan_scan(ix->dtype, ix->n, ix->d, ix->ld, 1, 1, ix->num_cus, &plan) != 0)
         return fail(MTR_ERR_INVALID, "no scan shape for this shard");
     if ((rc = begin_use(ix, ix->stream)) != MTR_OK) return rc;
-    hipEvent_t e0, e1;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
     HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
+    hipError_t err = hipEventCreate(&e1);
     unsigned int* sink = reinterpret_cast<unsigned int*>(ix->flag) + 8;   // spare words of the flag block
     double sum = 0.0;
-    for (int r = 0; r < reps + 1; ++r) {   // the first launch warms up
-        HIP_TRY(hipEventRecord(e0, ix->stream));
-        HIP_TRY(mtr::launch_scan_read_only(ix->rows, ix->dtype, ix->n, ix->ld, ix->d, plan, sink, ix->stream));
-        HIP_TRY(hipEventRecord(e1, ix->stream));
-        HIP_TRY(hipEventSynchronize(e1));
+    for (int r = 0; r < reps + 1 && err == hipSuccess; ++r) {   // the first launch warms up
         float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        if ((err = hipEventRecord(e0, ix->stream)) != hipSuccess) break;
+        if ((err = mtr::launch_scan_read_only(ix->rows, ix->dtype, ix->n, ix->ld, ix->d, plan, sink, ix->stream)) != hipSuccess) break;
+        if ((err = hipEventRecord(e1, ix->stream)) != hipSuccess) break;
+        if ((err = hipEventSynchronize(e1)) != hipSuccess) break;
+        if ((err = hipEventElapsedTime(&ms, e0, e1)) != hipSuccess) break;
         if (r > 0) sum += ms;
     }
     (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
+    if (e1) (void)hipEventDestroy(e1);
+    if (err != hipSuccess) {
+        (void)hipStreamSynchronize(ix->stream);
+        ix->used = false;
+        return fail(MTR_ERR_HIP, "timing the scan's loads: %s", hipGetErrorString(err));
+    }
     ix->used = false;   // every launch above was waited for
     *avg_ms = (float)(sum / reps);
     return MTR_OK;
