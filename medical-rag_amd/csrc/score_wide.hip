@@ -384,22 +384,37 @@ __global__ __launch_bounds__(kWideThreads, 2) void score_filter_wide_kernel(Wide
                     unsigned long long* qkeys = my_keys + (size_t)ql * kWideSubs * a.cap;
                     // Three scores per test (v_max3): a branch costs more than the compare,
                     // and with some thousand scores per query reaching the floor, about one
-                    // group in three holds one in some lane.
+                    // group in three holds one in some lane.  Inside the branch (one lane
+                    // active as a rule, some 15 times per wave and tile) the lane's first hit
+                    // is picked with selects and stored once; only a lane with two or three
+                    // hits in one group, which is rare, goes through a second branch.
+                    using u32x2 = __attribute__((ext_vector_type(2))) unsigned int;
 #pragma unroll
                     for (int g = 0; g < 32; g += 3) {
-                        float mx = acc[g >> 2][nn][g & 3];
-#pragma unroll
-                        for (int j = g + 1; j < g + 3 && j < 32; ++j) mx = fmaxf(mx, acc[j >> 2][nn][j & 3]);
+                        const float v0 = acc[g >> 2][nn][g & 3];
+                        const float v1 = g + 1 < 32 ? acc[(g + 1) >> 2][nn][(g + 1) & 3] : -__builtin_huge_valf();
+                        const float v2 = g + 2 < 32 ? acc[(g + 2) >> 2][nn][(g + 2) & 3] : -__builtin_huge_valf();
+                        const float mx = fmaxf(fmaxf(v0, v1), v2);
                         if (__builtin_expect(mx >= thr[nn], 0)) {
-#pragma unroll
-                            for (int j = g; j < g + 3 && j < 32; ++j) {
-                                const float v = acc[j >> 2][nn][j & 3];
-                                if (v >= thr[nn]) {
-                                    // (row, raw score bits), wrapping around in a full list: the count
-                                    // tells the selection kernel that the list is incomplete.
-                                    using u32x2 = __attribute__((ext_vector_type(2))) unsigned int;
+                            // (row, raw score bits), wrapping around in a full list: the count
+                            // tells the selection kernel that the list is incomplete.
+                            const int r0 = (g >> 2) * 16 + (g & 3), r1 = ((g + 1) >> 2) * 16 + ((g + 1) & 3),
+                                      r2 = ((g + 2) >> 2) * 16 + ((g + 2) & 3);
+                            const bool h0 = v0 >= thr[nn], h1 = v1 >= thr[nn], h2 = v2 >= thr[nn];
+                            const float vs = h0 ? v0 : h1 ? v1 : v2;
+                            const int rs = h0 ? r0 : h1 ? r1 : r2;
+                            *reinterpret_cast<u32x2*>(qkeys + (cnt[nn] & cap_mask)) =
+                                u32x2{(unsigned int)(row_base + rs), __float_as_uint(vs)};
+                            ++cnt[nn];
+                            if (__builtin_expect((h0 && (h1 || h2)) || (h1 && h2), 0)) {
+                                if (h0 && h1) {
                                     *reinterpret_cast<u32x2*>(qkeys + (cnt[nn] & cap_mask)) =
-                                        u32x2{(unsigned int)(row_base + (j >> 2) * 16 + (j & 3)), __float_as_uint(v)};
+                                        u32x2{(unsigned int)(row_base + r1), __float_as_uint(v1)};
+                                    ++cnt[nn];
+                                }
+                                if ((h0 || h1) && h2) {
+                                    *reinterpret_cast<u32x2*>(qkeys + (cnt[nn] & cap_mask)) =
+                                        u32x2{(unsigned int)(row_base + r2), __float_as_uint(v2)};
                                     ++cnt[nn];
                                 }
                             }
