@@ -270,6 +270,25 @@ def test_integer_data_is_exact_with_many_ties(native, store):
 
 
 @pytest.mark.parametrize("store", ["fp32", "bf16"])
+def test_long_result_lists_on_a_full_grid(native, store):
+    """k above 256 (the scan with long per-wave lists, then the streaming merge of
+    every workgroup's list) on a shard large enough for one workgroup per CU, ids
+    beyond 2^32.  Integer data, so ids and scores must equal the oracle bit for
+    bit, ties included; single queries and a pass of several, k up to the maximum."""
+    rng = np.random.default_rng(4242)
+    n, d = 150_000, 48
+    corpus = rng.integers(-3, 4, size=(n, d)).astype(np.float32)
+    shard = native.DeviceShard.from_host(corpus, store_dtype=store, normalize=False, row_offset=7_000_000_000)
+    for b, k in ((1, 1024), (1, 257), (3, 700), (6, 300)):
+        queries = rng.integers(-3, 4, size=(b, d)).astype(np.float32)
+        idx, score = shard.search(queries, k=k, metric="ip")
+        want_i, want_s = orc.search(queries, corpus, k, metric="ip")
+        assert (idx == want_i + 7_000_000_000).all(), (b, k)
+        assert (score == want_s.astype(np.float32)).all(), (b, k)
+    shard.close()
+
+
+@pytest.mark.parametrize("store", ["fp32", "bf16"])
 def test_stored_rows_are_normalised(rag, store):
     rng = np.random.default_rng(9)
     corpus = (rng.standard_normal((300, 130)) * 5).astype(np.float32)
