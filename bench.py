@@ -235,25 +235,32 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         if args.rehearse_on_one_gpu:
+            # gloo carries the id, barriers and timing; the library's communicator is rehearsed too when
+            # MTR_RCCL_LIBRARY names a collective library that accepts several ranks on one device
+            # (the tests' shared-memory stand-in, tests/rccl_double)
             dist.init_process_group("gloo", rank=rank, world_size=world)
+            want_comm = bool(os.environ.get("MTR_RCCL_LIBRARY")) and not args.torch_exchange
+            flag_device = "cpu"
         else:
             # torch.distributed carries the RCCL unique id, the barriers and the max over ranks of the
             # elapsed time; the searches' all-gather runs on the library's own communicator.
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
-            if not args.torch_exchange:
-                # Either every rank exchanges through the library's communicator or none does.
-                try:
-                    comm = native.Comm.from_process_group(local_rank)
-                except Exception as exc:
-                    comm_note = f"{type(exc).__name__}: {exc}"
-                    print(f"[bench] rank {rank}: no library communicator ({comm_note})", file=sys.stderr, flush=True)
-                agreed = torch.tensor([1 if comm is not None else 0], device=f"cuda:{local_rank}", dtype=torch.int32)
-                dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
-                if int(agreed.item()) == 0:
-                    if comm is not None:
-                        comm.close()
-                        comm = None
-                    comm_note = comm_note or "another rank could not create it"
+            want_comm = not args.torch_exchange
+            flag_device = f"cuda:{local_rank}"
+        if want_comm:
+            # Either every rank exchanges through the library's communicator or none does.
+            try:
+                comm = native.Comm.from_process_group(local_rank)
+            except Exception as exc:
+                comm_note = f"{type(exc).__name__}: {exc}"
+                print(f"[bench] rank {rank}: no library communicator ({comm_note})", file=sys.stderr, flush=True)
+            agreed = torch.tensor([1 if comm is not None else 0], device=flag_device, dtype=torch.int32)
+            dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+            if int(agreed.item()) == 0:
+                if comm is not None:
+                    comm.close()
+                    comm = None
+                comm_note = comm_note or "another rank could not create it"
 
     w = dict(WORKLOADS[args.workload])
     if args.rows:
@@ -410,7 +417,9 @@ def main():
             "config": {"workload": w["name"], "rows": rows, "dim": dim, "batch": batch, "k": k,
                        "rows_per_gpu": hi - lo,
                        "parallelism": f"row-shard x{world}" + (" + RCCL all-gather + k-way merge" if world > 1 else ""),
-                       "exchange": ("library RCCL communicator (mtr_sharded_search_device)" if comm is not None
+                       "exchange": ("REHEARSAL: all ranks on one GPU, the library's communicator over " + os.environ.get("MTR_RCCL_LIBRARY", "?")
+                                    if comm is not None and args.rehearse_on_one_gpu
+                                    else "library RCCL communicator (mtr_sharded_search_device)" if comm is not None
                                     else "REHEARSAL: all ranks on one GPU, gloo" if args.rehearse_on_one_gpu and exchanging
                                     else "torch.distributed" + (f" (library communicator unavailable: {comm_note})" if comm_note else "")
                                     if exchanging else None),

@@ -15,6 +15,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -52,6 +53,16 @@ const Rccl* rccl() {
     static Rccl r = [] {
         Rccl v;
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        // MTR_RCCL_LIBRARY: the one to use, by path (a particular RCCL build; the tests' stand-in
+        // for several ranks on one GPU)
+        const char* chosen = getenv("MTR_RCCL_LIBRARY");
+        if (chosen && *chosen) {
+            v.handle = dlopen(chosen, RTLD_NOW | RTLD_LOCAL);
+            if (!v.handle) {
+                snprintf(v.why, sizeof(v.why), "cannot load MTR_RCCL_LIBRARY=%s: %s", chosen, dlerror());
+                return v;
+            }
+        }
         for (const char* n : names)
             if (!v.handle) v.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
         for (const char* n : names)

@@ -166,3 +166,17 @@ def test_one_hip_runtime_whatever_the_import_order():
     run = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0, run.stderr
     assert run.stdout.startswith("1 "), run.stdout
+
+
+def test_rccl_stand_in_is_built_and_exports_what_the_library_resolves():
+    """tests/rccl_double: the shared-memory stand-in behind the multi-rank GPU
+    tests must be in the tree (built by __graft_entry__.build / make double)."""
+    import ctypes
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_double", "librccl_double.so")
+    assert os.path.exists(path), "make -C medical-rag_amd/csrc double"
+    from medical_rag_amd import _native
+    _native.lib()                    # maps the HIP runtime the stand-in links against
+    lib = ctypes.CDLL(path)
+    for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclAllGather", "ncclGetErrorString"):
+        assert hasattr(lib, name), name

@@ -818,6 +818,88 @@ def test_two_processes_search_their_shards_and_merge():
         assert dict(ret) == {0: True, 1: True}
 
 
+def _double_rank_worker(rank, world, port, ret, n):
+    import os
+    import sys
+    import torch
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      MTR_RCCL_LIBRARY=os.path.join(root, "tests", "rccl_double", "librccl_double.so"))
+    dist.init_process_group("gloo", rank=rank, world_size=world)    # carries the communicator id only
+    try:
+        from medical_rag_amd import _native
+        from medical_rag_amd.sharded import ShardedIndex, shard_bounds
+        from oracle import local_rag_oracle as orc
+        torch.cuda.set_device(0)
+        rng = np.random.default_rng(123)
+        d = 192
+        corpus = rng.integers(-3, 4, size=(n, d)).astype(np.float32)      # integer data: exact scores, ties everywhere
+        corpus[n - 1] = corpus[0]                                          # a tie between the first and the last rank
+        lo, hi = shard_bounds(n, world, rank)
+        shard = None
+        if hi > lo:
+            shard = _native.DeviceShard.from_host(corpus[lo:hi], store_dtype="bf16", normalize=False, row_offset=lo)
+        comm = _native.Comm.from_process_group(0)
+        index = ShardedIndex(shard, comm=comm)
+        ok = index.world_size == world and comm.world == world and comm.rank == rank
+        # one C call per search: local top-k into the send block, all-gather, merge
+        for b, k in ((1, 10), (40, 7), (1, 10), (3, 33), (130, 5), (2, 300)):
+            queries = rng.integers(-3, 4, size=(b, d)).astype(np.float32)
+            q = torch.from_numpy(queries).cuda()
+            gi, gs = index.search_device(q, k=k, metric="ip")
+            torch.cuda.synchronize()
+            wi, ws = orc.search(queries, corpus, k, metric="ip")
+            ok = ok and bool((gi.cpu().numpy() == wi).all()) and bool((gs.cpu().numpy() == ws.astype(np.float32)).all())
+        # the pipelined form: exchange and merge on a side stream, several searches pending
+        for depth in (2, 3):
+            batches = [rng.integers(-3, 4, size=(4, d)).astype(np.float32) for _ in range(7)]
+            pending = [index.search_device_async(torch.from_numpy(x).cuda(), k=9, metric="ip", depth=depth) for x in batches[:depth - 1]]
+            got = []
+            for x in batches[depth - 1:]:
+                pending.append(index.search_device_async(torch.from_numpy(x).cuda(), k=9, metric="ip", depth=depth))
+                gi, gs = pending.pop(0).result()
+                torch.cuda.synchronize()
+                got.append((gi.cpu().numpy().copy(), gs.cpu().numpy().copy()))
+            while pending:
+                gi, gs = pending.pop(0).result()
+                torch.cuda.synchronize()
+                got.append((gi.cpu().numpy().copy(), gs.cpu().numpy().copy()))
+            for x, (gi, gs) in zip(batches, got):
+                wi, ws = orc.search(x, corpus, 9, metric="ip")
+                ok = ok and bool((gi == wi).all()) and bool((gs == ws.astype(np.float32)).all())
+        ret[rank] = bool(ok)
+        if shard is not None:
+            shard.close()
+        comm.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 30011), (3, 20000), (3, 2)])
+def test_library_communicator_with_several_ranks_over_a_stand_in(world, n):
+    """csrc/comm_rccl.hip with MORE THAN ONE RANK: block layout, buffer rotation, the
+    merge over every rank's gathered block, ranks without rows (2 rows over 3 ranks),
+    the fused call and the pipelined form.  RCCL itself refuses two ranks on one
+    GPU, so the collective underneath is the tests' shared-memory stand-in
+    (tests/rccl_double, chosen with MTR_RCCL_LIBRARY): this checks the library's
+    code around the all-gather, not RCCL.  Every rank must end with the unsharded
+    oracle's answer, bit for bit on integer data."""
+    import os
+    import socket
+    import torch.multiprocessing as mp
+    double = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_double", "librccl_double.so")
+    assert os.path.exists(double), "build it with `make -C medical-rag_amd/csrc double`"
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_double_rank_worker, args=(world, port, ret, n), nprocs=world, join=True)
+        assert dict(ret) == {r: True for r in range(world)}
+
+
 def test_merge_reads_packed_gathered_buffer(native):
     """The exchange buffer layout of the multi-GPU path: every rank's ids and
     scores in one block, merged through strided views without copies."""
