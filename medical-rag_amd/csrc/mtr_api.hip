@@ -249,16 +249,16 @@ int end_use(mtr_index* ix, hipStream_t stream) {
 }
 
 // Smallest batch that goes to the matrix-core kernel; below it the HBM-bound
-// scan handles the batch in passes of up to four (bf16) or eight (fp32) queries.
+// scan handles the batch in one pass of up to four queries.
 // Measured hand-over (1M rows, ms per search): bf16 x 1024 -- scan 0.315 for one
 // query, 0.349 / 0.360 / 0.367 for two / three / four, matrix cores (32-query
 // tiles) 0.349 for two to sixteen; fp32 x 768 -- scan 0.46 / 0.49 / 0.51 / 0.51 for
-// one to four and 0.55-0.57 for five to eight, matrix cores (fp32 MFMA) 0.61 for
-// three, 0.58-0.59 for four to eight, 0.60 for twelve (two scan passes: 1.1).
+// one to four and 0.55-0.58 for five to eight (one pass of eight), matrix cores
+// (16-query tiles of v_mfma_f32_16x16x4_f32) 0.51 for two to sixteen.
 int mfma_min_batch(int dtype) {
     const int forced = mtr::tuning().mfma_min_batch;
     if (forced > 0) return forced;
-    return dtype == MTR_BF16 ? 2 : 9;
+    return dtype == MTR_BF16 ? 2 : 5;
 }
 
 // Every how many row tiles one goes into the sampling launch (< 2: no sample).

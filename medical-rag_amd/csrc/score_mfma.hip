@@ -186,6 +186,33 @@ __device__ __forceinline__ void mfma_step(float, const char* sa, const char* sb,
     }
 }
 
+// The 16-query tile of fp32 shards (batches up to 16): v_mfma_f32_16x16x4_f32, half
+// the matrix-core work of a 32-column tile that would be half padding -- and the
+// fp32 matrix rate, not HBM, is what bounds these batches.  A wave owns 32 rows x
+// 16 queries as two 16 x 16 tiles.  Lane l supplies row (or query) l % 16 and, for
+// the j-th instruction of chunk c, K element 8 (l / 16) + 4 c + j of the step (the
+// order of K inside a step is free as long as both operands agree); it ends up with
+// rows 4 (l / 16) + r, r = 0..3, of query l % 16.  Blocked summation as above.
+__device__ __forceinline__ void mfma_step16(const char* sa, const char* sb, int row_off, int lane, f32x4v (&acc)[2]) {
+    const int g = lane >> 4, c16 = lane & 15;
+    f32x4v fb[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) fb[c] = read_frag_f32(sb, c16, 2 * g + c);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        f32x4v fa[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) fa[c] = read_frag_f32(sa, row_off + m * 16 + c16, 2 * g + c);
+        f32x4v part = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) part = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[c][j], fb[c][j], part, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[m][r] += part[r];
+    }
+}
+
 // Re-selection of one query's buffer.
 //   load_keys:      c entries (c <= 64*E) into registers, 0 for empty slots.
 //   finish_select:  keeps between k and k + slack of them, compacted to the
@@ -294,6 +321,42 @@ __device__ __forceinline__ void append_above(f32x16& tile, float thr, int ql, lo
     for (int r = 0; r < 16; ++r) tile[r] = 0.f;
 }
 
+// The same for one 16 x 16 tile of the 16-query form: query lane % 16, rows row0 + r.
+template <int CAP>
+__device__ __forceinline__ void append_above16(f32x4v& tile, float thr, int ql, long long row0, bool last_tile,
+                                               const MfmaArgs& a, int* cnt_lds, unsigned long long* my_buf) {
+    const float mx = fmaxf(fmaxf(tile[0], tile[1]), fmaxf(tile[2], tile[3]));
+    if (__any(mx > thr)) {
+        unsigned int pass = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pass |= (tile[r] > thr) ? (1u << r) : 0u;
+        if (last_tile) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (row0 + r >= a.n) pass &= ~(1u << r);
+        }
+        int slot = 0;
+        if (pass) slot = atomicAdd(&cnt_lds[ql], __popc(pass));
+        unsigned int any_r = pass;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) any_r |= __shfl_xor(any_r, off, 64);
+        any_r = __builtin_amdgcn_readfirstlane(any_r);
+        unsigned long long* dst = my_buf + (size_t)ql * CAP;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (any_r & (1u << r)) {
+                if (pass & (1u << r)) {
+                    if (MTR_TIMING(a) & 2) slot &= CAP - 1;
+                    if (slot < CAP) dst[slot] = pack_key(tile[r], (int)(row0 + r));
+                    ++slot;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tile[r] = 0.f;
+}
+
 // s_barrier without the drain of outstanding loads that __syncthreads() adds.
 __device__ __forceinline__ void barrier_keeping_loads() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -375,14 +438,16 @@ __global__ __launch_bounds__(TM == 256 ? 512 : 256, TM == 256 ? 1 : 2) void scor
     static_assert(TM == 128 || (TM == 256 && NS == 3), "the tall tile exists in the ring form only");
     static_assert(TNQ % (8 * (TM == 256 ? 8 : 4)) == 0 || TNQ / 8 < (TM == 256 ? 8 : 4),
                   "the query tile is staged in whole 8-row pieces: an equal number per wave, or one each by the first waves");
+    constexpr bool N16 = TNQ == 16;   // the 16-query form (see mfma_step16)
+    static_assert(!N16 || (sizeof(T) == 4 && NS == 2 && TM == 128), "the 16-query tile exists for fp32 shards, two buffers, 128-row tiles");
     constexpr int kThreads = TM == 256 ? 512 : 256;
     if (a.run_if && *a.run_if == 0) return;
     constexpr int TN = TNQ;
     constexpr int WAVES = kThreads / 64;
-    constexpr int WN = (TNQ == 32 || (TM == 256 && TNQ == 64)) ? 1 : 2;    // waves along the queries
+    constexpr int WN = (TNQ <= 32 || (TM == 256 && TNQ == 64)) ? 1 : 2;    // waves along the queries
     constexpr int WM = WAVES / WN;                          // ... and along the rows
     constexpr int MT = TM / (32 * WM);           // MFMA tiles per wave along the rows
-    constexpr int NT = TNQ / (32 * WN);          // ... and along the queries
+    constexpr int NT = N16 ? 1 : TNQ / (32 * WN);   // ... and along the queries (the 16-query form has its own accumulators)
     constexpr int QPW = TNQ / WAVES;             // queries each wave looks after
     static_assert(CAP >= 2 * TM, "a tile may append TM keys per query on top of k + slack kept ones");
     constexpr int kStageBytes = stage_bytes(TM, TNQ);
@@ -442,6 +507,7 @@ __global__ __launch_bounds__(TM == 256 ? 512 : 256, TM == 256 ? 1 : 2) void scor
         for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+    f32x4v acc16[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // 16-query form: rows row_off + 16 m + 4 (lane / 16) + r, query lane % 16
 
     const long long total_steps = my_tiles * ksteps;
     if constexpr (NS == 3) {
@@ -528,7 +594,9 @@ __global__ __launch_bounds__(TM == 256 ? 512 : 256, TM == 256 ? 1 : 2) void scor
             stage_tile<ROW_AUX, TM, WAVES>(a.rows, ntile * TM, a.n - 1, row_bytes, nks * kStepBytes, stage0 + (cur ^ 1) * kStageBytes, wave, lane);
             stage_tile<0, TNQ, WAVES>(qbase, 0, TN - 1, row_bytes, nks * kStepBytes, stage0 + (cur ^ 1) * kStageBytes + TM * kStepBytes, wave, lane);
         }
-        if (!(MTR_TIMING(a) & 32))
+        if constexpr (N16) {
+            mfma_step16(stage0 + cur * kStageBytes, stage0 + cur * kStageBytes + TM * kStepBytes, row_off, lane, acc16);
+        } else if (!(MTR_TIMING(a) & 32))
         mfma_step<MT, NT>(T{}, stage0 + cur * kStageBytes, stage0 + cur * kStageBytes + TM * kStepBytes, row_off, q_off,
                           lane, acc);
 
@@ -537,6 +605,19 @@ __global__ __launch_bounds__(TM == 256 ? 512 : 256, TM == 256 ? 1 : 2) void scor
             // Sampling launch: keep nothing but the tile's best score per query.  Rows
             // past the end of the matrix were staged as copies of the last row, so
             // they cannot raise a maximum.
+            if constexpr (N16) {
+                float mx = -__builtin_huge_valf();
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        mx = fmaxf(mx, acc16[m][r]);
+                        acc16[m][r] = 0.f;
+                    }
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                if (lane < 16) atomicMax(&best_lds[lane], order_f32(mx));
+            } else
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 float mx = -__builtin_huge_valf();
@@ -554,6 +635,13 @@ __global__ __launch_bounds__(TM == 256 ? 512 : 256, TM == 256 ? 1 : 2) void scor
             // Scores of the 128-row x TNQ-query tile are complete: append what clears each query's floor.
             const long long row_base = ptile * TM + row_off + 4 * (lane >> 5);
             const bool last_tile = (ptile + 1) * TM > a.n;
+            if constexpr (N16) {
+                const int ql = lane & 15;
+                const float thr = fmaxf(floor_lds[ql], unorder_f32(order_f32(shared_lds[ql]) - 1u));
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+                    append_above16<CAP>(acc16[m], thr, ql, ptile * TM + row_off + m * 16 + 4 * (lane >> 4), last_tile, a, cnt_lds, my_buf);
+            } else
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 const int ql = q_off + n * 32 + (lane & 31);
@@ -603,7 +691,7 @@ __global__ __launch_bounds__(TM == 256 ? 512 : 256, TM == 256 ? 1 : 2) void scor
 int plan_mfma(int dtype, int64_t n, int ld, int b, int k, int num_cus, int sampling, MfmaPlan* plan) {
     const int esize = dtype == 0 ? 4 : 2;
     if ((ld * esize) % kStepBytes != 0 || ld * esize < 2 * kStepBytes || k < 1 || k > 256 || b < 1 || n < 1) return -1;
-    plan->tnq = b <= 32 ? 32 : b <= 64 ? 64 : 128;
+    plan->tnq = (dtype == 0 && b <= 16) ? 16 : b <= 32 ? 32 : b <= 64 ? 64 : 128;   // (16: fp32 shards only, see mfma_step16)
     // A shard of few row tiles cannot fill the CUs with one workgroup per (row
     // tile, query tile) pair: narrower query tiles give more, shorter workgroups
     // (4032 x 4096 fp32, 34 queries: 32 workgroups of 64 queries 0.222 ms, 64 of 32
@@ -613,7 +701,7 @@ int plan_mfma(int dtype, int64_t n, int ld, int b, int k, int num_cus, int sampl
         while (plan->tnq > 32 && row_tiles * ((b + plan->tnq - 1) / plan->tnq) < num_cus) plan->tnq /= 2;
     }
     const Tuning& tn = tuning();
-    if (tn.mfma_tnq == 32 || tn.mfma_tnq == 64 || tn.mfma_tnq == 128) plan->tnq = tn.mfma_tnq;
+    if (tn.mfma_tnq == 32 || tn.mfma_tnq == 64 || tn.mfma_tnq == 128 || (tn.mfma_tnq == 16 && dtype == 0)) plan->tnq = tn.mfma_tnq;
     plan->n_qtiles = (b + plan->tnq - 1) / plan->tnq;
     // Row loads carry the streaming (nt) policy when every row byte is fetched
     // once per launch -- a single query tile -- and the rows exceed the Infinity
@@ -638,6 +726,7 @@ int plan_mfma(int dtype, int64_t n, int ld, int b, int k, int num_cus, int sampl
     if (tall_ok) tm = 256;
     if (tn.mfma_tile_rows) tm = (tn.mfma_tile_rows == 256 && tall_ok) ? 256 : kTileRows;
     if (tm == kTileRows && plan->tnq == 128) plan->stages = 2;
+    if (plan->tnq == 16) plan->stages = 2;
     plan->cap = (k <= 32 && tm == 128) ? 256 : 512;
     if ((tn.mfma_cap == 256 || tn.mfma_cap == 512) && k + tm <= tn.mfma_cap) plan->cap = tn.mfma_cap;
     plan->slack = (plan->cap - tm - k) / 4;
@@ -650,7 +739,7 @@ int plan_mfma(int dtype, int64_t n, int ld, int b, int k, int num_cus, int sampl
     // Measured best with two buffers: 3 for the 32-query tile (four fit), 2 for
     // the 64- and 128-query tiles.  Two ring workgroups fit a CU's LDS, one of
     // the eight-wave 256-row form.
-    long long per_cu = tm == 256 ? 1 : plan->stages == 3 ? 2 : plan->tnq == 32 ? 3 : 2;
+    long long per_cu = tm == 256 ? 1 : plan->stages == 3 ? 2 : plan->tnq <= 32 ? 3 : 2;
     if (tn.mfma_per_cu > 0 && tm != 256) per_cu = tn.mfma_per_cu;
     // rounded down: a grid a few workgroups above per_cu * CUs runs those in a second round
     long long ranges = per_cu * num_cus / plan->n_qtiles;
@@ -731,6 +820,14 @@ hipError_t launch_score_mfma(const void* rows, int dtype, int64_t n, int ld, con
         case 64: return launch(&score_topk_mfma_kernel<T, 256, 64, false, 2, 3>);                     \
         case 65: return launch(&score_topk_mfma_kernel<T, 512, 64, false, 2, 3>);                     \
         default: return hipErrorInvalidValue;                                                         \
+    }
+    if (plan.tnq == 16) {
+        if (dtype != 0 || plan.stages != 2 || plan.tm != kTileRows) return hipErrorInvalidValue;
+        if (a.tile_max != nullptr) return launch(&score_topk_mfma_kernel<float, 256, 16, true, 0, 2>);
+        if (plan.cap == 256) return plan.stream_rows ? launch(&score_topk_mfma_kernel<float, 256, 16, false, 2, 2>)
+                                                     : launch(&score_topk_mfma_kernel<float, 256, 16, false, 0, 2>);
+        return plan.stream_rows ? launch(&score_topk_mfma_kernel<float, 512, 16, false, 2, 2>)
+                                : launch(&score_topk_mfma_kernel<float, 512, 16, false, 0, 2>);
     }
     if (plan.tm == 256) {
         if (plan.stages != 3 || plan.cap != 512 || dtype != 2 || a.tile_max != nullptr) return hipErrorInvalidValue;

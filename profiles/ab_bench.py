@@ -3,7 +3,7 @@
 under load, so builds are only comparable side by side): same synthetic shard,
 same queries, per-launch HIP-event time of the scoring kernel(s) through the
 entry points both builds export.
-usage: ab_bench.py LIB_A LIB_B rows dim batch k [reps]"""
+usage: ab_bench.py LIB_A LIB_B rows dim batch k [reps [bf16|fp32]]"""
 import ctypes as C
 import json
 import sys
@@ -28,6 +28,7 @@ def main():
     paths = sys.argv[1:3]
     rows, dim, batch, k = (int(x) for x in sys.argv[3:7])
     reps = int(sys.argv[7]) if len(sys.argv) > 7 else 30
+    store = 0 if (len(sys.argv) > 8 and sys.argv[8] == "fp32") else 2
     gen = torch.Generator(device="cuda").manual_seed(1)
     queries = torch.randn((batch, dim), generator=gen, device="cuda")
     out_i = torch.empty((batch, k), dtype=torch.int64, device="cuda")
@@ -36,7 +37,7 @@ def main():
     handles = []
     for lib in libs:
         h = C.c_void_p()
-        assert lib.mtr_index_alloc(rows, dim, 2, 1, 0, 0, C.byref(h)) == 0, lib.mtr_last_error()
+        assert lib.mtr_index_alloc(rows, dim, store, 1, 0, 0, C.byref(h)) == 0, lib.mtr_last_error()
         g = torch.Generator(device="cuda").manual_seed(7)
         for r0 in range(0, rows, 262144):
             n = min(262144, rows - r0)
