@@ -695,10 +695,11 @@ int plan_mfma(int dtype, int64_t n, int ld, int b, int k, int num_cus, int sampl
     // A shard of few row tiles cannot fill the CUs with one workgroup per (row
     // tile, query tile) pair: narrower query tiles give more, shorter workgroups
     // (4032 x 4096 fp32, 34 queries: 32 workgroups of 64 queries 0.222 ms, 64 of 32
-    // queries 0.139 ms; the rows are read once more, out of L2).
+    // queries 0.130 ms, 96 of 16 queries 0.095 ms; the rows are read once more, out of L2).
     {
         const long long row_tiles = (n + kTileRows - 1) / kTileRows;
-        while (plan->tnq > 32 && row_tiles * ((b + plan->tnq - 1) / plan->tnq) < num_cus) plan->tnq /= 2;
+        const int narrowest = dtype == 0 ? 16 : 32;
+        while (plan->tnq > narrowest && row_tiles * ((b + plan->tnq - 1) / plan->tnq) < num_cus) plan->tnq /= 2;
     }
     const Tuning& tn = tuning();
     if (tn.mfma_tnq == 32 || tn.mfma_tnq == 64 || tn.mfma_tnq == 128 || (tn.mfma_tnq == 16 && dtype == 0)) plan->tnq = tn.mfma_tnq;
