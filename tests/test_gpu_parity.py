@@ -269,6 +269,36 @@ def test_integer_data_is_exact_with_many_ties(native, store):
     shard.close()
 
 
+def test_fp32_sixteen_query_tiles(native):
+    """fp32 shards, batches of 5..16 (and small shards with more queries): the
+    16-query tile on v_mfma_f32_16x16x4_f32 -- plain, with streaming row loads,
+    behind a sampling launch (its 16-query maxima form), ragged last tiles, k
+    below and above the rows of a tile.  Integer data: ids and scores equal the
+    oracle bit for bit."""
+    rng = np.random.default_rng(1616)
+    for n, d, b, k, opts in ((1000, 64, 5, 10, {}), (4032, 96, 34, 10, {}), (777, 32, 16, 100, {}),
+                             (50_000, 128, 9, 7, dict(mfma_stream_rows=1)), (50_000, 128, 16, 33, dict(mfma_sample_stride=3)),
+                             (20_001, 64, 12, 1, dict(mfma_sample_stride=2, mfma_stream_rows=1)), (129, 32, 16, 256, {}),
+                             (3, 32, 7, 5, {}), (60_000, 256, 2, 10, dict(mfma_min_batch=2))):
+        corpus = rng.integers(-3, 4, size=(n, d)).astype(np.float32)
+        queries = rng.integers(-3, 4, size=(b, d)).astype(np.float32)
+        shard = native.DeviceShard.from_host(corpus, store_dtype="fp32", normalize=False)
+        with native.options(**opts):
+            idx, score = shard.search(queries, k=k, metric="ip")
+        want_i, want_s = orc.search(queries, corpus, k, metric="ip")
+        assert (idx == want_i).all(), (n, d, b, k, opts)
+        assert (score == want_s.astype(np.float32)).all(), (n, d, b, k, opts)
+        shard.close()
+    # real-valued data: within the fp32 tolerance of the float64 oracle
+    n, d, b, k = 30_000, 768, 13, 10
+    corpus = rng.standard_normal((n, d)).astype(np.float32)
+    queries = rng.standard_normal((b, d)).astype(np.float32)
+    shard = native.DeviceShard.from_host(corpus, store_dtype="fp32")
+    idx, score = shard.search(queries, k=k)
+    check_topk(idx, score, orc.scores(queries, corpus), k, 1e-6)
+    shard.close()
+
+
 @pytest.mark.parametrize("store", ["fp32", "bf16"])
 def test_long_result_lists_on_a_full_grid(native, store):
     """k above 256 (the scan with long per-wave lists, then the streaming merge of
