@@ -102,13 +102,15 @@ __device__ __forceinline__ void stage_tile(const char* base, long long row0, lon
                                            int k0_bytes, char* lds, int wave, int lane) {
     // ROWS rows x 128 bytes.  One wave instruction fills 8 rows; lane L writes
     // LDS position (row L/8, slot L%8) and fetches chunk (L%8) ^ (L/8) of it.
-    // Fewer 8-row pieces than waves (a 32-query tile under eight waves): the first
-    // ROWS / 8 waves take one piece each, the others none.
-    constexpr int PER_WAVE = ROWS >= 8 * WAVES ? ROWS / (8 * WAVES) : 1;
-    if (ROWS < 8 * WAVES && wave >= ROWS / 8) return;
+    // Wave w takes pieces w, w + WAVES, ...: an equal number each when the pieces
+    // divide evenly (the forms with counted waits rely on that, or on "one piece
+    // for the first waves only"), else the first waves take one more.
+    constexpr int PIECES = ROWS / 8;
+    constexpr int ROUNDS = (PIECES + WAVES - 1) / WAVES;
 #pragma unroll
-    for (int i = 0; i < PER_WAVE; ++i) {
-        const int t = wave * PER_WAVE + i;
+    for (int i = 0; i < ROUNDS; ++i) {
+        const int t = PIECES % WAVES == 0 ? wave * ROUNDS + i : wave + i * WAVES;
+        if (PIECES % WAVES != 0 && t >= PIECES) break;   // wave-uniform
         const int r = t * 8 + (lane >> 3);
         long long row = row0 + r;
         row = row < row_max ? row : row_max;
@@ -186,30 +188,36 @@ __device__ __forceinline__ void mfma_step(float, const char* sa, const char* sb,
     }
 }
 
-// The 16-query tile of fp32 shards (batches up to 16): v_mfma_f32_16x16x4_f32, half
-// the matrix-core work of a 32-column tile that would be half padding -- and the
-// fp32 matrix rate, not HBM, is what bounds these batches.  A wave owns 32 rows x
-// 16 queries as two 16 x 16 tiles.  Lane l supplies row (or query) l % 16 and, for
+// The 16- and 48-query tiles of fp32 shards (batches up to 16, and of 33..48):
+// v_mfma_f32_16x16x4_f32, so that a 32- or 64-column tile is not half or a quarter
+// padding -- the fp32 matrix rate, not HBM, is what bounds these batches.  A wave
+// owns 32 rows x 16 NQ queries as 2 x NQ tiles of 16 x 16.  Lane l supplies row (or query) l % 16 and, for
 // the j-th instruction of chunk c, K element 8 (l / 16) + 4 c + j of the step (the
 // order of K inside a step is free as long as both operands agree); it ends up with
 // rows 4 (l / 16) + r, r = 0..3, of query l % 16.  Blocked summation as above.
-__device__ __forceinline__ void mfma_step16(const char* sa, const char* sb, int row_off, int lane, f32x4v (&acc)[2]) {
+template <int NQ>
+__device__ __forceinline__ void mfma_step16(const char* sa, const char* sb, int row_off, int lane, f32x4v (&acc)[2][NQ]) {
     const int g = lane >> 4, c16 = lane & 15;
-    f32x4v fb[2];
+    f32x4v fb[NQ][2];
 #pragma unroll
-    for (int c = 0; c < 2; ++c) fb[c] = read_frag_f32(sb, c16, 2 * g + c);
+    for (int n = 0; n < NQ; ++n)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) fb[n][c] = read_frag_f32(sb, n * 16 + c16, 2 * g + c);
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
         f32x4v fa[2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) fa[c] = read_frag_f32(sa, row_off + m * 16 + c16, 2 * g + c);
-        f32x4v part = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int n = 0; n < NQ; ++n) {
+            f32x4v part = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) part = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[c][j], fb[c][j], part, 0, 0, 0);
+            for (int c = 0; c < 2; ++c)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[m][r] += part[r];
+                for (int j = 0; j < 4; ++j) part = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[c][j], fb[n][c][j], part, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[m][n][r] += part[r];
+        }
     }
 }
 
@@ -436,15 +444,16 @@ template <typename T, int CAP, int TNQ, bool MAX_ONLY, int ROW_AUX, int NS, int 
 __global__ __launch_bounds__(TM == 256 ? 512 : 256, TM == 256 ? 1 : 2) void score_topk_mfma_kernel(MfmaArgs a) {
     static_assert(NS == 2 || (NS == 3 && !MAX_ONLY), "the ring form exists for the full launch only");
     static_assert(TM == 128 || (TM == 256 && NS == 3), "the tall tile exists in the ring form only");
-    static_assert(TNQ % (8 * (TM == 256 ? 8 : 4)) == 0 || TNQ / 8 < (TM == 256 ? 8 : 4),
-                  "the query tile is staged in whole 8-row pieces: an equal number per wave, or one each by the first waves");
-    constexpr bool N16 = TNQ == 16;   // the 16-query form (see mfma_step16)
-    static_assert(!N16 || (sizeof(T) == 4 && NS == 2 && TM == 128), "the 16-query tile exists for fp32 shards, two buffers, 128-row tiles");
+    static_assert(NS == 2 || TNQ % (8 * (TM == 256 ? 8 : 4)) == 0 || TNQ / 8 < (TM == 256 ? 8 : 4),
+                  "counted waits: the query tile's 8-row pieces are an equal number per wave, or one each for the first waves");
+    constexpr bool N16 = TNQ == 16 || TNQ == 48;   // the forms on 16 x 16 tiles (see mfma_step16)
+    constexpr int NQ16 = N16 ? TNQ / 16 : 1;
+    static_assert(!N16 || (sizeof(T) == 4 && NS == 2 && TM == 128), "the 16 x 16 forms exist for fp32 shards, two buffers, 128-row tiles");
     constexpr int kThreads = TM == 256 ? 512 : 256;
     if (a.run_if && *a.run_if == 0) return;
     constexpr int TN = TNQ;
     constexpr int WAVES = kThreads / 64;
-    constexpr int WN = (TNQ <= 32 || (TM == 256 && TNQ == 64)) ? 1 : 2;    // waves along the queries
+    constexpr int WN = (TNQ <= 32 || N16 || (TM == 256 && TNQ == 64)) ? 1 : 2;    // waves along the queries
     constexpr int WM = WAVES / WN;                          // ... and along the rows
     constexpr int MT = TM / (32 * WM);           // MFMA tiles per wave along the rows
     constexpr int NT = N16 ? 1 : TNQ / (32 * WN);   // ... and along the queries (the 16-query form has its own accumulators)
@@ -507,7 +516,11 @@ __global__ __launch_bounds__(TM == 256 ? 512 : 256, TM == 256 ? 1 : 2) void scor
         for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-    f32x4v acc16[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // 16-query form: rows row_off + 16 m + 4 (lane / 16) + r, query lane % 16
+    f32x4v acc16[2][NQ16];   // 16 x 16 forms: rows row_off + 16 m + 4 (lane / 16) + r, query 16 n + lane % 16
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < NQ16; ++n) acc16[m][n] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
     const long long total_steps = my_tiles * ksteps;
     if constexpr (NS == 3) {
@@ -595,7 +608,7 @@ __global__ __launch_bounds__(TM == 256 ? 512 : 256, TM == 256 ? 1 : 2) void scor
             stage_tile<0, TNQ, WAVES>(qbase, 0, TN - 1, row_bytes, nks * kStepBytes, stage0 + (cur ^ 1) * kStageBytes + TM * kStepBytes, wave, lane);
         }
         if constexpr (N16) {
-            mfma_step16(stage0 + cur * kStageBytes, stage0 + cur * kStageBytes + TM * kStepBytes, row_off, lane, acc16);
+            mfma_step16<NQ16>(stage0 + cur * kStageBytes, stage0 + cur * kStageBytes + TM * kStepBytes, row_off, lane, acc16);
         } else if (!(MTR_TIMING(a) & 32))
         mfma_step<MT, NT>(T{}, stage0 + cur * kStageBytes, stage0 + cur * kStageBytes + TM * kStepBytes, row_off, q_off,
                           lane, acc);
@@ -606,17 +619,20 @@ __global__ __launch_bounds__(TM == 256 ? 512 : 256, TM == 256 ? 1 : 2) void scor
             // past the end of the matrix were staged as copies of the last row, so
             // they cannot raise a maximum.
             if constexpr (N16) {
-                float mx = -__builtin_huge_valf();
 #pragma unroll
-                for (int m = 0; m < 2; ++m)
+                for (int n = 0; n < NQ16; ++n) {
+                    float mx = -__builtin_huge_valf();
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        mx = fmaxf(mx, acc16[m][r]);
-                        acc16[m][r] = 0.f;
-                    }
-                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-                if (lane < 16) atomicMax(&best_lds[lane], order_f32(mx));
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            mx = fmaxf(mx, acc16[m][n][r]);
+                            acc16[m][n][r] = 0.f;
+                        }
+                    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                    if (lane < 16) atomicMax(&best_lds[n * 16 + lane], order_f32(mx));
+                }
             } else
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
@@ -636,11 +652,14 @@ __global__ __launch_bounds__(TM == 256 ? 512 : 256, TM == 256 ? 1 : 2) void scor
             const long long row_base = ptile * TM + row_off + 4 * (lane >> 5);
             const bool last_tile = (ptile + 1) * TM > a.n;
             if constexpr (N16) {
-                const int ql = lane & 15;
-                const float thr = fmaxf(floor_lds[ql], unorder_f32(order_f32(shared_lds[ql]) - 1u));
 #pragma unroll
-                for (int m = 0; m < 2; ++m)
-                    append_above16<CAP>(acc16[m], thr, ql, ptile * TM + row_off + m * 16 + 4 * (lane >> 4), last_tile, a, cnt_lds, my_buf);
+                for (int n = 0; n < NQ16; ++n) {
+                    const int ql = n * 16 + (lane & 15);
+                    const float thr = fmaxf(floor_lds[ql], unorder_f32(order_f32(shared_lds[ql]) - 1u));
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+                        append_above16<CAP>(acc16[m][n], thr, ql, ptile * TM + row_off + m * 16 + 4 * (lane >> 4), last_tile, a, cnt_lds, my_buf);
+                }
             } else
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
@@ -691,7 +710,7 @@ __global__ __launch_bounds__(TM == 256 ? 512 : 256, TM == 256 ? 1 : 2) void scor
 int plan_mfma(int dtype, int64_t n, int ld, int b, int k, int num_cus, int sampling, MfmaPlan* plan) {
     const int esize = dtype == 0 ? 4 : 2;
     if ((ld * esize) % kStepBytes != 0 || ld * esize < 2 * kStepBytes || k < 1 || k > 256 || b < 1 || n < 1) return -1;
-    plan->tnq = (dtype == 0 && b <= 16) ? 16 : b <= 32 ? 32 : b <= 64 ? 64 : 128;   // (16: fp32 shards only, see mfma_step16)
+    plan->tnq = (dtype == 0 && b <= 16) ? 16 : b <= 32 ? 32 : (dtype == 0 && b <= 48) ? 48 : b <= 64 ? 64 : 128;   // (16, 48: fp32 shards only, see mfma_step16)
     // A shard of few row tiles cannot fill the CUs with one workgroup per (row
     // tile, query tile) pair: narrower query tiles give more, shorter workgroups
     // (4032 x 4096 fp32, 34 queries: 32 workgroups of 64 queries 0.222 ms, 64 of 32
@@ -699,10 +718,10 @@ int plan_mfma(int dtype, int64_t n, int ld, int b, int k, int num_cus, int sampl
     {
         const long long row_tiles = (n + kTileRows - 1) / kTileRows;
         const int narrowest = dtype == 0 ? 16 : 32;
-        while (plan->tnq > narrowest && row_tiles * ((b + plan->tnq - 1) / plan->tnq) < num_cus) plan->tnq /= 2;
+        while (plan->tnq > narrowest && row_tiles * ((b + plan->tnq - 1) / plan->tnq) < num_cus) plan->tnq = plan->tnq == 48 ? 16 : plan->tnq / 2;
     }
     const Tuning& tn = tuning();
-    if (tn.mfma_tnq == 32 || tn.mfma_tnq == 64 || tn.mfma_tnq == 128 || (tn.mfma_tnq == 16 && dtype == 0)) plan->tnq = tn.mfma_tnq;
+    if (tn.mfma_tnq == 32 || tn.mfma_tnq == 64 || tn.mfma_tnq == 128 || ((tn.mfma_tnq == 16 || tn.mfma_tnq == 48) && dtype == 0)) plan->tnq = tn.mfma_tnq;
     plan->n_qtiles = (b + plan->tnq - 1) / plan->tnq;
     // Row loads carry the streaming (nt) policy when every row byte is fetched
     // once per launch -- a single query tile -- and the rows exceed the Infinity
@@ -727,7 +746,7 @@ int plan_mfma(int dtype, int64_t n, int ld, int b, int k, int num_cus, int sampl
     if (tall_ok) tm = 256;
     if (tn.mfma_tile_rows) tm = (tn.mfma_tile_rows == 256 && tall_ok) ? 256 : kTileRows;
     if (tm == kTileRows && plan->tnq == 128) plan->stages = 2;
-    if (plan->tnq == 16) plan->stages = 2;
+    if (plan->tnq == 16 || plan->tnq == 48) plan->stages = 2;
     plan->cap = (k <= 32 && tm == 128) ? 256 : 512;
     if ((tn.mfma_cap == 256 || tn.mfma_cap == 512) && k + tm <= tn.mfma_cap) plan->cap = tn.mfma_cap;
     plan->slack = (plan->cap - tm - k) / 4;
@@ -822,14 +841,18 @@ hipError_t launch_score_mfma(const void* rows, int dtype, int64_t n, int ld, con
         case 65: return launch(&score_topk_mfma_kernel<T, 512, 64, false, 2, 3>);                     \
         default: return hipErrorInvalidValue;                                                         \
     }
-    if (plan.tnq == 16) {
-        if (dtype != 0 || plan.stages != 2 || plan.tm != kTileRows) return hipErrorInvalidValue;
-        if (a.tile_max != nullptr) return launch(&score_topk_mfma_kernel<float, 256, 16, true, 0, 2>);
-        if (plan.cap == 256) return plan.stream_rows ? launch(&score_topk_mfma_kernel<float, 256, 16, false, 2, 2>)
-                                                     : launch(&score_topk_mfma_kernel<float, 256, 16, false, 0, 2>);
-        return plan.stream_rows ? launch(&score_topk_mfma_kernel<float, 512, 16, false, 2, 2>)
-                                : launch(&score_topk_mfma_kernel<float, 512, 16, false, 0, 2>);
+#define MTR_MFMA_PICK16(TNQ16)                                                                                      \
+    {                                                                                                                \
+        if (dtype != 0 || plan.stages != 2 || plan.tm != kTileRows) return hipErrorInvalidValue;                     \
+        if (a.tile_max != nullptr) return launch(&score_topk_mfma_kernel<float, 256, TNQ16, true, 0, 2>);            \
+        if (plan.cap == 256) return plan.stream_rows ? launch(&score_topk_mfma_kernel<float, 256, TNQ16, false, 2, 2>) \
+                                                     : launch(&score_topk_mfma_kernel<float, 256, TNQ16, false, 0, 2>); \
+        return plan.stream_rows ? launch(&score_topk_mfma_kernel<float, 512, TNQ16, false, 2, 2>)                    \
+                                : launch(&score_topk_mfma_kernel<float, 512, TNQ16, false, 0, 2>);                   \
     }
+    if (plan.tnq == 16) MTR_MFMA_PICK16(16)
+    if (plan.tnq == 48) MTR_MFMA_PICK16(48)
+#undef MTR_MFMA_PICK16
     if (plan.tm == 256) {
         if (plan.stages != 3 || plan.cap != 512 || dtype != 2 || a.tile_max != nullptr) return hipErrorInvalidValue;
         if (plan.tnq == 32) return launch(&score_topk_mfma_kernel<bf16_t, 512, 32, false, 2, 3, 256>);

@@ -270,8 +270,8 @@ def test_integer_data_is_exact_with_many_ties(native, store):
 
 
 def test_fp32_sixteen_query_tiles(native):
-    """fp32 shards, batches of 5..16 (and small shards with more queries): the
-    16-query tile on v_mfma_f32_16x16x4_f32 -- plain, with streaming row loads,
+    """fp32 shards, batches of 5..16 and 33..48 (and small shards with more queries):
+    the 16- and 48-query tiles on v_mfma_f32_16x16x4_f32 -- plain, with streaming row loads,
     behind a sampling launch (its 16-query maxima form), ragged last tiles, k
     below and above the rows of a tile.  Integer data: ids and scores equal the
     oracle bit for bit."""
@@ -279,7 +279,9 @@ def test_fp32_sixteen_query_tiles(native):
     for n, d, b, k, opts in ((1000, 64, 5, 10, {}), (4032, 96, 34, 10, {}), (777, 32, 16, 100, {}),
                              (50_000, 128, 9, 7, dict(mfma_stream_rows=1)), (50_000, 128, 16, 33, dict(mfma_sample_stride=3)),
                              (20_001, 64, 12, 1, dict(mfma_sample_stride=2, mfma_stream_rows=1)), (129, 32, 16, 256, {}),
-                             (3, 32, 7, 5, {}), (60_000, 256, 2, 10, dict(mfma_min_batch=2))):
+                             (3, 32, 7, 5, {}), (60_000, 256, 2, 10, dict(mfma_min_batch=2)),
+                             (70_000, 128, 34, 10, {}), (70_000, 64, 48, 40, dict(mfma_sample_stride=3, mfma_stream_rows=1)),
+                             (40_001, 96, 41, 1, dict(mfma_stream_rows=1)), (70_000, 32, 33, 200, {})):
         corpus = rng.integers(-3, 4, size=(n, d)).astype(np.float32)
         queries = rng.integers(-3, 4, size=(b, d)).astype(np.float32)
         shard = native.DeviceShard.from_host(corpus, store_dtype="fp32", normalize=False)
