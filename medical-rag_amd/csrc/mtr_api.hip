@@ -340,14 +340,17 @@ int enqueue_mfma(mtr_index* ix, S& sc, const mtr::MfmaPlan& plan, const void* de
         // (its query tiles may be narrower than the full launch's: both index queries and floors by query number)
     }
     const size_t q_row_bytes = (size_t)ix->ld * dtype_size(ix->dtype);
-    const int64_t q_rows = std::max<int64_t>((int64_t)plan.n_qtiles * plan.tnq, use_wide ? (int64_t)wide.n_qtiles * 256 : 0);
+    // Queries padded to whole tiles: the sampling launch may cut the batch into tiles of another
+    // width than the full launch (fewer rows, narrower tiles), and its padded count can be the larger.
+    const int padded_q = std::max(plan.n_qtiles * plan.tnq, stride >= 2 ? samp.n_qtiles * samp.tnq : 0);
+    const int64_t q_rows = std::max<int64_t>((int64_t)padded_q, use_wide ? (int64_t)wide.n_qtiles * 256 : 0);
     const size_t qbytes = (size_t)q_rows * q_row_bytes;
     const void* q_old = sc.keeps_query_tiles() ? ix->scratch[kQTiles].p : nullptr;
     if ((rc = sc.need(kQTiles, qbytes)) != MTR_OK) return rc;
     if ((rc = sc.need(kMfmaCand, plan.cand_bytes)) != MTR_OK) return rc;
     if ((rc = sc.need(kCandS, (size_t)b * plan.n_ranges * k * 4)) != MTR_OK) return rc;
     if ((rc = sc.need(kCandI, (size_t)b * plan.n_ranges * k * 4)) != MTR_OK) return rc;
-    const int floor_words = std::max(plan.n_qtiles * plan.tnq, use_wide ? wide.n_qtiles * 256 : 0);
+    const int floor_words = std::max(padded_q, use_wide ? wide.n_qtiles * 256 : 0);
     if ((rc = sc.need(kMfmaFloor, (size_t)floor_words * 4)) != MTR_OK) return rc;
     size_t tile_max_bytes = 0;
     if (use_wide) {
@@ -388,7 +391,7 @@ int enqueue_mfma(mtr_index* ix, S& sc, const mtr::MfmaPlan& plan, const void* de
     int* lists_i = static_cast<int*>(sc.p[kCandI]);
     if (stride >= 2) {
         unsigned int* tile_max = static_cast<unsigned int*>(sc.p[kTileMax]);
-        const mtr::MfmaPass sampling{stride, tile_max, nullptr};
+        const mtr::MfmaPass sampling{stride, tile_max, nullptr, floor_words};
         HIP_TRY(mtr::launch_score_mfma(ix->rows, ix->dtype, ix->n, ix->ld, qbuf, b, k, samp, sampling,
                                        sc.p[kMfmaCand], floors, lists_s, lists_i, stream));
         HIP_TRY(mtr::launch_floor_from_tile_max(tile_max, (int)samp.n_tiles, b, k, floors, stream));
@@ -411,7 +414,7 @@ int enqueue_mfma(mtr_index* ix, S& sc, const mtr::MfmaPlan& plan, const void* de
                                         dev_out_score, overflow, stream));
         HIP_TRY(mtr::launch_reset_floors_if(floors, floor_words, overflow, stream));
     }
-    const mtr::MfmaPass all{1, nullptr, overflow};
+    const mtr::MfmaPass all{1, nullptr, overflow, floor_words};
     HIP_TRY(mtr::launch_score_mfma(ix->rows, ix->dtype, ix->n, ix->ld, qbuf, b, k, plan, all, sc.p[kMfmaCand],
                                    floors, lists_s, lists_i, stream));
     if (profiling && !use_wide) HIP_TRY(hipEventRecord(e1, stream));

@@ -170,6 +170,7 @@ struct MfmaPass {
     int tile_stride;
     unsigned int* tile_max;   // [n_qtiles*tnq][plan.n_tiles] order-preserving score bits, or NULL
     const int* run_if;        // not NULL: the launch does nothing while this device word is 0
+    int padded_queries;       // queries the caller's query, floor and tile_max buffers hold (the launch needs n_qtiles * tnq)
 };
 
 // rows x queries on the matrix cores with fused top-k, both in the shard's storage type

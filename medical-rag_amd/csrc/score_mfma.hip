@@ -446,7 +446,7 @@ __global__ __launch_bounds__(TM == 256 ? 512 : 256, TM == 256 ? 1 : 2) void scor
     static_assert(TM == 128 || (TM == 256 && NS == 3), "the tall tile exists in the ring form only");
     static_assert(NS == 2 || TNQ % (8 * (TM == 256 ? 8 : 4)) == 0 || TNQ / 8 < (TM == 256 ? 8 : 4),
                   "counted waits: the query tile's 8-row pieces are an equal number per wave, or one each for the first waves");
-    constexpr bool N16 = TNQ == 16 || TNQ == 48;   // the forms on 16 x 16 tiles (see mfma_step16)
+    constexpr bool N16 = TNQ % 32 != 0 || TNQ == 96;   // the forms on 16 x 16 tiles: 16, 48, 80, 96 and 112 queries (see mfma_step16)
     constexpr int NQ16 = N16 ? TNQ / 16 : 1;
     static_assert(!N16 || (sizeof(T) == 4 && NS == 2 && TM == 128), "the 16 x 16 forms exist for fp32 shards, two buffers, 128-row tiles");
     constexpr int kThreads = TM == 256 ? 512 : 256;
@@ -710,18 +710,31 @@ __global__ __launch_bounds__(TM == 256 ? 512 : 256, TM == 256 ? 1 : 2) void scor
 int plan_mfma(int dtype, int64_t n, int ld, int b, int k, int num_cus, int sampling, MfmaPlan* plan) {
     const int esize = dtype == 0 ? 4 : 2;
     if ((ld * esize) % kStepBytes != 0 || ld * esize < 2 * kStepBytes || k < 1 || k > 256 || b < 1 || n < 1) return -1;
-    plan->tnq = (dtype == 0 && b <= 16) ? 16 : b <= 32 ? 32 : (dtype == 0 && b <= 48) ? 48 : b <= 64 ? 64 : 128;   // (16, 48: fp32 shards only, see mfma_step16)
+    // Query-tile widths: 32, 64 and 128 (32 x 32 MFMA tiles, both storage types); fp32 shards,
+    // whose batches are bound by the fp32 matrix rate, also have 16, 48, 80, 96 and 112
+    // (16 x 16 tiles, see mfma_step16) so that a tile is never more than 15 columns of padding.
+    // The batch is cut into the fewest tiles of at most 128, and those are as narrow as they can be.
+    static const int kWidthsF32[] = {16, 32, 48, 64, 80, 96, 112, 128};
+    static const int kWidthsBf16[] = {32, 64, 128};
+    const int* widths = dtype == 0 ? kWidthsF32 : kWidthsBf16;
+    const int n_widths = dtype == 0 ? 8 : 3;
+    int wi = 0;
+    {
+        const int tiles = (b + 127) / 128, per_tile = (b + tiles - 1) / tiles;
+        while (wi + 1 < n_widths && widths[wi] < per_tile) ++wi;
+    }
     // A shard of few row tiles cannot fill the CUs with one workgroup per (row
     // tile, query tile) pair: narrower query tiles give more, shorter workgroups
     // (4032 x 4096 fp32, 34 queries: 32 workgroups of 64 queries 0.222 ms, 64 of 32
     // queries 0.130 ms, 96 of 16 queries 0.095 ms; the rows are read once more, out of L2).
     {
         const long long row_tiles = (n + kTileRows - 1) / kTileRows;
-        const int narrowest = dtype == 0 ? 16 : 32;
-        while (plan->tnq > narrowest && row_tiles * ((b + plan->tnq - 1) / plan->tnq) < num_cus) plan->tnq = plan->tnq == 48 ? 16 : plan->tnq / 2;
+        while (wi > 0 && row_tiles * ((b + widths[wi] - 1) / widths[wi]) < num_cus) --wi;
     }
+    plan->tnq = widths[wi];
     const Tuning& tn = tuning();
-    if (tn.mfma_tnq == 32 || tn.mfma_tnq == 64 || tn.mfma_tnq == 128 || ((tn.mfma_tnq == 16 || tn.mfma_tnq == 48) && dtype == 0)) plan->tnq = tn.mfma_tnq;
+    for (int i = 0; i < n_widths; ++i)
+        if (tn.mfma_tnq == widths[i]) plan->tnq = tn.mfma_tnq;
     plan->n_qtiles = (b + plan->tnq - 1) / plan->tnq;
     // Row loads carry the streaming (nt) policy when every row byte is fetched
     // once per launch -- a single query tile -- and the rows exceed the Infinity
@@ -746,7 +759,7 @@ int plan_mfma(int dtype, int64_t n, int ld, int b, int k, int num_cus, int sampl
     if (tall_ok) tm = 256;
     if (tn.mfma_tile_rows) tm = (tn.mfma_tile_rows == 256 && tall_ok) ? 256 : kTileRows;
     if (tm == kTileRows && plan->tnq == 128) plan->stages = 2;
-    if (plan->tnq == 16 || plan->tnq == 48) plan->stages = 2;
+    if (plan->tnq % 32 != 0 || plan->tnq == 96) plan->stages = 2;   // the 16 x 16 forms have two buffers
     plan->cap = (k <= 32 && tm == 128) ? 256 : 512;
     if ((tn.mfma_cap == 256 || tn.mfma_cap == 512) && k + tm <= tn.mfma_cap) plan->cap = tn.mfma_cap;
     plan->slack = (plan->cap - tm - k) / 4;
@@ -776,6 +789,8 @@ int plan_mfma(int dtype, int64_t n, int ld, int b, int k, int num_cus, int sampl
 hipError_t launch_score_mfma(const void* rows, int dtype, int64_t n, int ld, const void* queries, int b, int k,
                              const MfmaPlan& plan, const MfmaPass& pass, void* cand_buf, unsigned int* shared_floor,
                              float* out_s, int* out_i, hipStream_t stream) {
+    // the kernels index queries, floors and per-tile maxima up to n_qtiles * tnq, padding included
+    if (plan.n_qtiles * plan.tnq > pass.padded_queries || b > plan.n_qtiles * plan.tnq) return hipErrorInvalidValue;
     MfmaArgs a;
     a.rows = static_cast<const char*>(rows);
     a.n = n;
@@ -852,6 +867,9 @@ hipError_t launch_score_mfma(const void* rows, int dtype, int64_t n, int ld, con
     }
     if (plan.tnq == 16) MTR_MFMA_PICK16(16)
     if (plan.tnq == 48) MTR_MFMA_PICK16(48)
+    if (plan.tnq == 80) MTR_MFMA_PICK16(80)
+    if (plan.tnq == 96) MTR_MFMA_PICK16(96)
+    if (plan.tnq == 112) MTR_MFMA_PICK16(112)
 #undef MTR_MFMA_PICK16
     if (plan.tm == 256) {
         if (plan.stages != 3 || plan.cap != 512 || dtype != 2 || a.tile_max != nullptr) return hipErrorInvalidValue;

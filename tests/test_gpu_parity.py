@@ -270,8 +270,10 @@ def test_integer_data_is_exact_with_many_ties(native, store):
 
 
 def test_fp32_sixteen_query_tiles(native):
-    """fp32 shards, batches of 5..16 and 33..48 (and small shards with more queries):
-    the 16- and 48-query tiles on v_mfma_f32_16x16x4_f32 -- plain, with streaming row loads,
+    """fp32 shards: the query tiles of 16, 48, 80, 96 and 112 on v_mfma_f32_16x16x4_f32
+    (batches of 5..16, 33..48, 65..112, 129.. in several such tiles, and small shards,
+    which take narrower tiles; a sampling launch may cut the batch into tiles of
+    another width than the full launch) -- plain, with streaming row loads,
     behind a sampling launch (its 16-query maxima form), ragged last tiles, k
     below and above the rows of a tile.  Integer data: ids and scores equal the
     oracle bit for bit."""
@@ -281,7 +283,9 @@ def test_fp32_sixteen_query_tiles(native):
                              (20_001, 64, 12, 1, dict(mfma_sample_stride=2, mfma_stream_rows=1)), (129, 32, 16, 256, {}),
                              (3, 32, 7, 5, {}), (60_000, 256, 2, 10, dict(mfma_min_batch=2)),
                              (70_000, 128, 34, 10, {}), (70_000, 64, 48, 40, dict(mfma_sample_stride=3, mfma_stream_rows=1)),
-                             (40_001, 96, 41, 1, dict(mfma_stream_rows=1)), (70_000, 32, 33, 200, {})):
+                             (40_001, 96, 41, 1, dict(mfma_stream_rows=1)), (70_000, 32, 33, 200, {}),
+                             (131_072, 64, 65, 10, dict(mfma_sample_stride=5)), (60_001, 128, 90, 33, dict(mfma_sample_stride=2)),
+                             (131_072, 32, 112, 5, dict(mfma_sample_stride=5, mfma_stream_rows=1)), (40_000, 64, 200, 10, {})):
         corpus = rng.integers(-3, 4, size=(n, d)).astype(np.float32)
         queries = rng.integers(-3, 4, size=(b, d)).astype(np.float32)
         shard = native.DeviceShard.from_host(corpus, store_dtype="fp32", normalize=False)
@@ -291,13 +295,14 @@ def test_fp32_sixteen_query_tiles(native):
         assert (idx == want_i).all(), (n, d, b, k, opts)
         assert (score == want_s.astype(np.float32)).all(), (n, d, b, k, opts)
         shard.close()
-    # real-valued data: within the fp32 tolerance of the float64 oracle
-    n, d, b, k = 30_000, 768, 13, 10
+    # real-valued data: within the fp32 tolerance of the float64 oracle (every 16 x 16 width: 16, 48, 80, 96, 112)
+    n, d, k = 40_000, 256, 10
     corpus = rng.standard_normal((n, d)).astype(np.float32)
-    queries = rng.standard_normal((b, d)).astype(np.float32)
     shard = native.DeviceShard.from_host(corpus, store_dtype="fp32")
-    idx, score = shard.search(queries, k=k)
-    check_topk(idx, score, orc.scores(queries, corpus), k, 1e-6)
+    for b in (13, 40, 70, 96, 112, 130, 200):
+        queries = rng.standard_normal((b, d)).astype(np.float32)
+        idx, score = shard.search(queries, k=k)
+        check_topk(idx, score, orc.scores(queries, corpus), k, 1e-6)
     shard.close()
 
 
