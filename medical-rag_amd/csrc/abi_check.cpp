@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/medtutor_retrieval.h"
+#include "mtr_device.h"   // launch plans (host functions): their invariants are checked below
 
 static int failures = 0;
 #define EXPECT(cond)                                                       \
@@ -66,9 +67,44 @@ static void json_reader_checks() {
     EXPECT(accepted == 3);
 }
 
+// What the matrix-core kernels assume of a launch plan, over many shapes, for the
+// full launch and for sampling launches over a part of the rows: the padded batch
+// covers the batch, the LDS fits a CU, a tile's appends fit a candidate buffer, the
+// tile width exists for the storage type, the row ranges cover every tile.
+static void plan_checks() {
+    const int bs[] = {1, 2, 5, 9, 16, 17, 32, 33, 34, 48, 49, 64, 65, 80, 81, 96, 97, 112, 113, 128, 129, 130, 200, 257, 1000, 4096};
+    const long long ns[] = {1, 127, 128, 129, 1000, 4032, 20000, 60001, 131072, 1000000, 12500000};
+    const int ks[] = {1, 10, 33, 100, 129, 256};
+    const int lds[] = {64, 128, 192, 768, 1024, 4096};
+    long long checked = 0;
+    for (int dtype : {0, 2})
+        for (long long n : ns)
+            for (int b : bs)
+                for (int k : ks)
+                    for (int ld : lds) {
+                        mtr::MfmaPlan p;
+                        if (mtr::plan_mfma(dtype, n, ld, b, k, 256, 0, &p) != 0) continue;
+                        ++checked;
+                        const bool sixteen = p.tnq % 32 != 0 || p.tnq == 96;
+                        EXPECT(p.n_qtiles * p.tnq >= b && p.lds <= 160 * 1024 && p.cap >= 2 * p.tm && k + p.tm + p.slack <= p.cap &&
+                               p.slack >= 0 && p.n_ranges >= 1 && p.tiles_per_range * p.n_ranges >= p.n_tiles &&
+                               p.grid == p.n_qtiles * p.n_ranges && p.tnq % 16 == 0 && p.tnq >= 16 && p.tnq <= 128 &&
+                               (dtype == 0 || !sixteen) && (p.tm == 128 || (p.tm == 256 && p.stages == 3 && dtype == 2)) &&
+                               (!sixteen || (p.stages == 2 && p.tm == 128)));
+                        for (int stride : {2, 13, 200}) {
+                            const long long stiles = (n + 127) / 128, n_samp = (stiles + stride - 1) / stride;
+                            mtr::MfmaPlan s;
+                            EXPECT(mtr::plan_mfma(dtype, n_samp * 128, ld, b, k, 256, 1, &s) == 0 && s.tm == 128 && s.stages == 2 &&
+                                   s.n_qtiles * s.tnq >= b && s.lds <= 160 * 1024);
+                        }
+                    }
+    EXPECT(checked > 10000);
+}
+
 int main() {
     printf("%s\n", mtr_version());
     json_reader_checks();
+    plan_checks();
     mtr_index_t* ix = nullptr;
     EXPECT(mtr_index_alloc(0, 8, MTR_F32, 1, 0, 0, &ix) == MTR_ERR_INVALID && ix == nullptr);
     EXPECT(strlen(mtr_last_error()) > 0);
