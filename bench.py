@@ -366,9 +366,9 @@ def main():
         default_shape = world == 1 and not (args.rows or args.batch or args.k or args.dim)
         traffic, traffic_file = pmc_traffic(args.workload, default_shape)
         # The library hands batches of >= 2 (bf16) / 5 (fp32) queries to the matrix-core
-        # kernel when rows are a multiple of 128 bytes (>= 256) and k <= 256.
+        # kernel when rows are a multiple of 128 bytes and k <= 256.
         min_b = int(os.environ.get("MTR_MFMA_MIN_BATCH", "0") or 0) or (2 if store == "bf16" else 5)
-        on_mfma = batch >= min_b and k <= 256 and (dim * esize) % 128 == 0 and dim * esize >= 256
+        on_mfma = batch >= min_b and k <= 256 and (dim * esize) % 128 == 0 and dim * esize >= 128
         kernel = "score_topk_mfma_kernel" if on_mfma else "scan_topk_kernel"
         # bf16 shards of >= 1 GB: batches above 128 take the 256 x 256-tile kernel behind the sampling launch
         wide_min = int(os.environ.get("MTR_WIDE_MIN_BATCH", "129"))

@@ -75,7 +75,7 @@ static void plan_checks() {
     const int bs[] = {1, 2, 5, 9, 16, 17, 32, 33, 34, 48, 49, 64, 65, 80, 81, 96, 97, 112, 113, 128, 129, 130, 200, 257, 1000, 4096};
     const long long ns[] = {1, 127, 128, 129, 1000, 4032, 20000, 60001, 131072, 1000000, 12500000};
     const int ks[] = {1, 10, 33, 100, 129, 256};
-    const int lds[] = {64, 128, 192, 768, 1024, 4096};
+    const int lds[] = {32, 64, 128, 192, 768, 1024, 4096};
     long long checked = 0;
     for (int dtype : {0, 2})
         for (long long n : ns)

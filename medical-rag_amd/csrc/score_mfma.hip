@@ -709,7 +709,8 @@ __global__ __launch_bounds__(TM == 256 ? 512 : 256, TM == 256 ? 1 : 2) void scor
 
 int plan_mfma(int dtype, int64_t n, int ld, int b, int k, int num_cus, int sampling, MfmaPlan* plan) {
     const int esize = dtype == 0 ? 4 : 2;
-    if ((ld * esize) % kStepBytes != 0 || ld * esize < 2 * kStepBytes || k < 1 || k > 256 || b < 1 || n < 1) return -1;
+    if ((ld * esize) % kStepBytes != 0 || ld * esize < kStepBytes || k < 1 || k > 256 || b < 1 || n < 1) return -1;
+    const bool one_step = ld * esize == kStepBytes;   // rows of 128 bytes: one K step per tile, the two-buffer 128-row forms only
     // Query-tile widths: 32, 64 and 128 (32 x 32 MFMA tiles, both storage types); fp32 shards,
     // whose batches are bound by the fp32 matrix rate, also have 16, 48, 80, 96 and 112
     // (16 x 16 tiles, see mfma_step16) so that a tile is never more than 15 columns of padding.
@@ -750,7 +751,7 @@ int plan_mfma(int dtype, int64_t n, int ld, int b, int k, int num_cus, int sampl
     // 0.375 ms; fp32 shards are bound by the fp32 matrix rate there and lose 1-2 %
     // to the ring's two workgroups per CU).
     // The 128-query tile has the ring only in its 256-row form (below).
-    const bool tall_shape = dtype == 2 && k <= 128;   // 256-row tiles (eight waves): bf16, every tile width
+    const bool tall_shape = dtype == 2 && k <= 128 && !one_step;   // 256-row tiles (eight waves): bf16, every tile width
     plan->stages = (plan->stream_rows && dtype == 2 && (plan->tnq <= 64 || tall_shape)) ? 3 : 2;
     if (tn.mfma_stages) plan->stages = (!sampling && tn.mfma_stages == 3 && (plan->tnq <= 64 || tall_shape)) ? 3 : 2;
     // ... with 256-row tiles (eight waves) for the 64- and 128-query tiles (bf16, k <= 128).
@@ -759,7 +760,7 @@ int plan_mfma(int dtype, int64_t n, int ld, int b, int k, int num_cus, int sampl
     if (tall_ok) tm = 256;
     if (tn.mfma_tile_rows) tm = (tn.mfma_tile_rows == 256 && tall_ok) ? 256 : kTileRows;
     if (tm == kTileRows && plan->tnq == 128) plan->stages = 2;
-    if (plan->tnq % 32 != 0 || plan->tnq == 96) plan->stages = 2;   // the 16 x 16 forms have two buffers
+    if (plan->tnq % 32 != 0 || plan->tnq == 96 || one_step) plan->stages = 2;   // the 16 x 16 forms have two buffers
     plan->cap = (k <= 32 && tm == 128) ? 256 : 512;
     if ((tn.mfma_cap == 256 || tn.mfma_cap == 512) && k + tm <= tn.mfma_cap) plan->cap = tn.mfma_cap;
     plan->slack = (plan->cap - tm - k) / 4;

@@ -306,6 +306,23 @@ def test_fp32_sixteen_query_tiles(native):
     shard.close()
 
 
+def test_rows_of_one_k_step(native):
+    """Rows of exactly 128 bytes (64 bf16 or 32 fp32 values): one K step per tile on the
+    matrix-core path, plain and behind a sampling launch.  Integer data, bit for bit."""
+    rng = np.random.default_rng(128)
+    for store, n, d, b, k, opts in (("bf16", 5000, 64, 40, 10, {}), ("fp32", 5000, 32, 9, 10, {}), ("fp32", 777, 32, 34, 3, {}),
+                                    ("bf16", 131_072, 64, 130, 33, dict(mfma_sample_stride=5)),
+                                    ("fp32", 70_000, 32, 70, 5, dict(mfma_sample_stride=2)), ("bf16", 300, 64, 2, 256, {})):
+        corpus = rng.integers(-3, 4, size=(n, d)).astype(np.float32)
+        queries = rng.integers(-3, 4, size=(b, d)).astype(np.float32)
+        shard = native.DeviceShard.from_host(corpus, store_dtype=store, normalize=False)
+        with native.options(**opts):
+            idx, score = shard.search(queries, k=k, metric="ip")
+        want_i, want_s = orc.search(queries, corpus, k, metric="ip")
+        assert (idx == want_i).all() and (score == want_s.astype(np.float32)).all(), (store, n, d, b, k, opts)
+        shard.close()
+
+
 @pytest.mark.parametrize("store", ["fp32", "bf16"])
 def test_long_result_lists_on_a_full_grid(native, store):
     """k above 256 (the scan with long per-wave lists, then the streaming merge of
