@@ -368,7 +368,11 @@ def main():
         # The library hands batches of >= 2 (bf16) / 5 (fp32) queries to the matrix-core
         # kernel when rows are a multiple of 128 bytes and k <= 256.
         min_b = int(os.environ.get("MTR_MFMA_MIN_BATCH", "0") or 0) or (2 if store == "bf16" else 5)
-        on_mfma = batch >= min_b and k <= 256 and (dim * esize) % 128 == 0 and dim * esize >= 128
+        # (rows are stored with a stride of whole 128-byte steps when that pads at most an eighth)
+        per_step = 128 // esize
+        ld_step = -(-dim // per_step) * per_step
+        stride_bytes = ld_step * esize if (dim >= per_step and (ld_step - dim) * 8 <= dim) else -(-dim * esize // 16) * 16
+        on_mfma = batch >= min_b and k <= 256 and stride_bytes % 128 == 0 and stride_bytes >= 128
         kernel = "score_topk_mfma_kernel" if on_mfma else "scan_topk_kernel"
         # bf16 shards of >= 1 GB: batches above 128 take the 256 x 256-tile kernel behind the sampling launch
         wide_min = int(os.environ.get("MTR_WIDE_MIN_BATCH", "129"))

@@ -13,7 +13,8 @@
  *    returns a thread-local message for the last failing call.
  *  - An index handle owns one device-resident row shard on ONE GPU: rows are
  *    stored row-major, L2-normalised (when asked), fp32 or bf16, with the row
- *    stride padded to a multiple of 16 bytes.  Row ids reported by a search
+ *    stride padded to a multiple of 16 bytes (of 128 bytes when that adds at
+ *    most an eighth to the row).  Row ids reported by a search
  *    are  row_offset + local row  (int64), so shards of one corpus on several
  *    GPUs (one process per GPU) report global ids.
  *  - Result rows are ordered by (score descending, row id ascending); slots

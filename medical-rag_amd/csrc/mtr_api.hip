@@ -529,6 +529,14 @@ int mtr_index_alloc(int64_t n, int32_t d, int32_t store_dtype, int32_t normalize
     ix->row_offset = row_offset;
     const int epc = 16 / dtype_size(store_dtype);
     ix->ld = (d + epc - 1) / epc * epc;
+    // Rows of a multiple of 128 bytes can go to the matrix-core kernels (whole K steps); other
+    // widths are padded up to one when that adds at most an eighth to the row (300 fp32 values:
+    // 1200 -> 1280 bytes), else they stay with the scan, which reads only the data columns.
+    {
+        const int per_step = 128 / dtype_size(store_dtype);
+        const int ld_step = (d + per_step - 1) / per_step * per_step;
+        if (d >= per_step && (ld_step - d) * 8 <= d) ix->ld = ld_step;
+    }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) ix->num_cus = prop.multiProcessorCount;
     hipError_t e = hipMalloc(&ix->rows, (size_t)n * ix->ld * dtype_size(store_dtype));

@@ -17,7 +17,7 @@ t0 = time.time(); fails = 0
 for case in range(cases):
     store = str(rng.choice(["bf16", "fp32"]))
     n = int(rng.choice([1, 3, 127, 128, 129, 255, 256, 257, 511, 1000, 4097, 20000, 60001, 131072]))
-    d = int(rng.choice([1, 8, 32, 33, 64, 100, 128, 192, 256, 320, 768]))
+    d = int(rng.choice([1, 8, 32, 33, 64, 100, 128, 192, 200, 256, 300, 320, 768]))
     b = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 16, 31, 32, 33, 48, 64, 65, 80, 90, 112, 128, 129, 200, 257]))
     k = int(rng.choice([1, 2, 5, 10, 32, 33, 100, 128, 129, 256, 300]))
     opts = {}
