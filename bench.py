@@ -273,6 +273,10 @@ def main():
         w["k"] = args.k
     rows, dim, store, batch, k = w["rows"], w["dim"], w["store"], w["batch"], w["k"]
     esize = 2 if store == "bf16" else 4
+    if args.rows or args.dim or args.batch or args.k:
+        # an overridden shape is named by what actually runs, not by the workload it started from
+        w["name"] = (f"synthetic {rows}x{dim} {store} corpus, {batch} quer{'y' if batch == 1 else 'ies'}/batch, "
+                     f"exact top-{k} (workload {args.workload} with overrides)")
 
     gq = torch.Generator(device=f"cuda:{local_rank}").manual_seed(12345)
     queries = torch.randn((batch, dim), generator=gq, device=f"cuda:{local_rank}", dtype=torch.float32)

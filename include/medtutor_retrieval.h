@@ -37,6 +37,7 @@ extern "C" {
 
 typedef struct mtr_index mtr_index_t;
 typedef struct mtr_comm mtr_comm_t;
+typedef struct mtr_multi_index mtr_multi_index_t;
 typedef struct mtr_json_index mtr_json_index_t;
 
 enum {
@@ -129,7 +130,10 @@ int mtr_index_search_device_noalloc(mtr_index_t* index, const void* dev_queries,
  * held a NaN or infinity (*nonfinite = 1; its results are then meaningless, and
  * the reference's scorer raises ValueError: pipeline/utils/local_rag.py:77).
  * Waits for that search to finish.  After mtr_index_search_device_noalloc,
- * which records no event, the caller synchronises with its stream first. */
+ * which records no event, the caller synchronises with its stream first; the
+ * report is then that of the last execution of that call, also when it was
+ * captured into a HIP graph and replayed (each replay clears and sets a word
+ * of its own, no value is frozen into the graph). */
 int mtr_index_nonfinite(mtr_index_t* index, int32_t* nonfinite);
 
 /* k-way merge of per-shard candidate lists on GPU device_id: inputs are
@@ -167,7 +171,16 @@ void mtr_comm_destroy(mtr_comm_t* comm);
  * on this rank's shard, the all-gather, the merge; dev_out_* (b*k each) receive
  * the global top-k, identical on every rank.  index may be NULL for a rank that
  * holds no rows (it contributes padding).  Every rank passes the same queries,
- * b, k and metric.  Up to four calls may be in flight on different streams. */
+ * b, k and metric.  Up to four calls may be in flight on different streams.
+ * Failures.  A rank whose own search fails (bad arguments for its shard, no
+ * memory for its scratch) still enters the all-gather with a block of padding
+ * and runs the merge, so that the other ranks are not left waiting, and returns
+ * its error afterwards: the other ranks' results then lack that rank's rows, and
+ * it is for the failing rank's caller to stop the job.  A rank that cannot even
+ * get its exchange buffers (MTR_ERR_OOM from this call or from
+ * mtr_comm_exchange_merge_device) misses the collective: its communicator then
+ * fails every later call with MTR_ERR_COMM, and the peers' pending all-gather
+ * does not complete until their communicators are destroyed. */
 int mtr_sharded_search_device(mtr_index_t* index, mtr_comm_t* comm, const void* dev_queries,
                               int32_t q_dtype, int32_t b, int32_t k, int32_t metric,
                               int64_t* dev_out_idx, float* dev_out_score, void* stream);
@@ -178,6 +191,67 @@ int mtr_comm_exchange_merge_device(mtr_comm_t* comm, const int64_t* dev_local_id
                                    const float* dev_local_score, int32_t b, int32_t k_in,
                                    int32_t k_out, int64_t* dev_out_idx, float* dev_out_score,
                                    void* stream);
+
+/* ---- row-sharded search: ONE process, several GPUs --------------------------
+ * The reference's caller is one process holding one index object
+ * (pipeline/async_main.py:190-195 loads it, pipeline/utils/retrieval.py:70-76
+ * searches it inline).  A multi index is that one object for a corpus spread
+ * over the GPUs of a node: device_ids lists the GPUs (n_devices entries, 1-64),
+ * block i of the rows -- contiguous, n / n_devices rows each, the first
+ * n % n_devices blocks one more -- lives as an ordinary shard with global row
+ * ids on device_ids[i].  Queries arrive at, and results leave from,
+ * device_ids[0].  A search enqueues, from the calling thread and without
+ * waiting in between: the queries to every GPU, every block's local top-k on a
+ * stream of its own, ONE exchange of the packed b*k*12-byte candidate blocks,
+ * and the k-way merge on device_ids[0].
+ * exchange: MTR_EXCHANGE_RCCL = a grouped ncclAllGather over the communicators
+ * of ncclCommInitAll (xGMI; the devices must be distinct);
+ * MTR_EXCHANGE_COPY = one peer copy per block into device_ids[0]'s gather
+ * buffer behind an event (no RCCL needed; also what a list that names a device
+ * more than once uses, e.g. a test of the block logic on one GPU);
+ * MTR_EXCHANGE_AUTO = RCCL when the list holds several distinct devices and
+ * RCCL loads, copies otherwise.  Results are those of one shard holding all the
+ * rows: same order, same tie rule (lowest row first). */
+enum { MTR_EXCHANGE_AUTO = 0, MTR_EXCHANGE_COPY = 1, MTR_EXCHANGE_RCCL = 2 };
+int mtr_multi_index_alloc(int64_t n, int32_t d, int32_t store_dtype, int32_t normalize,
+                          const int32_t* device_ids, int32_t n_devices, int32_t exchange,
+                          mtr_multi_index_t** out);
+/* Host rows [row_start, row_start + n_rows) of the corpus into the blocks that
+ * hold them (src_dtype as for mtr_index_load_rows, MTR_ROWS_AS_STORED
+ * included); the parts of different GPUs are uploaded side by side. */
+int mtr_multi_index_load_rows(mtr_multi_index_t* index, int64_t row_start, const void* host_rows,
+                              int64_t n_rows, int32_t src_dtype);
+/* mtr_multi_index_alloc + mtr_multi_index_load_rows of all n rows: the
+ * multi-GPU counterpart of mtr_index_create (load_embeddings,
+ * pipeline/utils/local_rag.py:90-101). */
+int mtr_multi_index_create(const void* host_rows, int64_t n, int32_t d, int32_t src_dtype,
+                           int32_t store_dtype, int32_t normalize, const int32_t* device_ids,
+                           int32_t n_devices, int32_t exchange, mtr_multi_index_t** out);
+/* Exact top-k of b host queries over all blocks; blocks until out_idx[b*k] and
+ * out_score[b*k] (host) are filled.  Same contract as mtr_index_search
+ * (retrieve_top_index, pipeline/utils/local_rag.py:71-78, is b = k = 1). */
+int mtr_multi_index_search(mtr_multi_index_t* index, const void* queries, int32_t q_dtype,
+                           int32_t b, int32_t k, int32_t metric, int64_t* out_idx, float* out_score);
+/* The same with queries and outputs resident on device_ids[0], enqueued behind
+ * `stream` (a stream of that GPU) without synchronising: the caller's stream
+ * continues behind the merge.  Non-finite queries are reported by
+ * mtr_multi_index_nonfinite afterwards, as for mtr_index_search_device. */
+int mtr_multi_index_search_device(mtr_multi_index_t* index, const void* dev_queries, int32_t q_dtype,
+                                  int32_t b, int32_t k, int32_t metric, int64_t* dev_out_idx,
+                                  float* dev_out_score, void* stream);
+int mtr_multi_index_nonfinite(mtr_multi_index_t* index, int32_t* nonfinite);
+/* Shape, storage, number of blocks and the exchange form in use (never AUTO).
+ * Any out pointer may be NULL. */
+int mtr_multi_index_info(const mtr_multi_index_t* index, int64_t* n, int32_t* d, int32_t* store_dtype,
+                         int32_t* normalized, int32_t* n_blocks, int32_t* exchange);
+/* Block i: its shard (borrowed; NULL when the block holds no rows: fewer rows
+ * than blocks), GPU and row range [row_lo, row_hi). */
+int mtr_multi_index_block(mtr_multi_index_t* index, int32_t i, mtr_index_t** shard,
+                          int32_t* device_id, int64_t* row_lo, int64_t* row_hi);
+/* Rows [row_start, row_start + n_rows) as stored, fp32 (n_rows x d), host. */
+int mtr_multi_index_read_rows(mtr_multi_index_t* index, int64_t row_start, int64_t n_rows,
+                              float* host_out);
+void mtr_multi_index_destroy(mtr_multi_index_t* index);
 
 /* Encoder epilogue on GPU device_id: masked mean over the t tokens of each of
  * b sequences, then L2 normalisation (eps 1e-12), written as fp32 rows that

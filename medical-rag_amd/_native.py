@@ -20,6 +20,9 @@ MTR_ROWS_AS_STORED = 256
 MTR_COSINE, MTR_IP = 0, 1
 MTR_MAX_K = 1024
 
+MTR_EXCHANGE_AUTO, MTR_EXCHANGE_COPY, MTR_EXCHANGE_RCCL = 0, 1, 2
+EXCHANGES = {"auto": MTR_EXCHANGE_AUTO, "copy": MTR_EXCHANGE_COPY, "rccl": MTR_EXCHANGE_RCCL}
+
 METRICS = {"cosine": MTR_COSINE, "ip": MTR_IP}
 STORE_DTYPES = {"fp32": MTR_F32, "f32": MTR_F32, "float32": MTR_F32, "bf16": MTR_BF16, "bfloat16": MTR_BF16}
 
@@ -42,6 +45,17 @@ SIGNATURES = {
     "mtr_comm_destroy": (None, [_vp]),
     "mtr_sharded_search_device": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "mtr_comm_exchange_merge_device": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "mtr_multi_index_alloc": (_i32, [_i64, _i32, _i32, _i32, C.POINTER(_i32), _i32, _i32, _pp]),
+    "mtr_multi_index_load_rows": (_i32, [_vp, _i64, _vp, _i64, _i32]),
+    "mtr_multi_index_create": (_i32, [_vp, _i64, _i32, _i32, _i32, _i32, C.POINTER(_i32), _i32, _i32, _pp]),
+    "mtr_multi_index_search": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "mtr_multi_index_search_device": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "mtr_multi_index_nonfinite": (_i32, [_vp, C.POINTER(_i32)]),
+    "mtr_multi_index_info": (_i32, [_vp, C.POINTER(_i64), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32),
+                                    C.POINTER(_i32), C.POINTER(_i32)]),
+    "mtr_multi_index_block": (_i32, [_vp, _i32, _pp, C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i64)]),
+    "mtr_multi_index_read_rows": (_i32, [_vp, _i64, _i64, _vp]),
+    "mtr_multi_index_destroy": (None, [_vp]),
     "mtr_pool_normalize": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _vp]),
     "mtr_index_info": (_i32, [_vp, C.POINTER(_i64), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32),
                               C.POINTER(_i32), C.POINTER(_i64)]),
@@ -426,6 +440,153 @@ class DeviceShard:
     def close(self):
         if self._h is not None and self._h.value:
             lib().mtr_index_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MultiShard:
+    """One index whose row blocks sit on several GPUs, driven by this one
+    process (mtr_multi_index_t*): what load_embeddings builds when the
+    retriever is given a list of devices.  Same search surface as DeviceShard;
+    queries arrive at and results leave from the first device of the list."""
+
+    def __init__(self, handle):
+        self._h = handle
+        self._info = None
+
+    @classmethod
+    def alloc(cls, n, d, devices, store_dtype="fp32", normalize=True, exchange="auto"):
+        devs = (_i32 * len(devices))(*[int(x) for x in devices])
+        out = C.c_void_p()
+        check(lib().mtr_multi_index_alloc(int(n), int(d), STORE_DTYPES[store_dtype], int(bool(normalize)), devs,
+                                          len(devices), EXCHANGES[exchange], C.byref(out)))
+        return cls(out)
+
+    @classmethod
+    def from_host(cls, rows, devices, store_dtype="fp32", normalize=True, exchange="auto", as_stored=False,
+                  chunk_rows=None):
+        """rows: (n, d) float32 / float64 / uint16 bfloat16 bits, possibly a
+        memory map: streamed to the blocks in chunks of chunk_rows rows."""
+        rows = rows if isinstance(rows, np.ndarray) and rows.ndim == 2 else as_host_matrix(rows, "rows")
+        shard = cls.alloc(rows.shape[0], rows.shape[1], devices, store_dtype=store_dtype, normalize=normalize,
+                          exchange=exchange)
+        try:
+            if chunk_rows is None:
+                chunk_rows = max(1, (256 << 20) // max(1, rows.shape[1] * rows.dtype.itemsize))
+            for r0 in range(0, rows.shape[0], chunk_rows):
+                shard.load_host(r0, rows[r0:r0 + chunk_rows], as_stored=as_stored)
+        except Exception:
+            shard.close()
+            raise
+        return shard
+
+    def load_host(self, row_start, rows, as_stored=False):
+        rows = as_host_matrix(rows, "rows")
+        if rows.shape[1] != self.d:
+            raise ValueError(f"rows have {rows.shape[1]} columns, the index has {self.d}")
+        code = np_dtype_code(rows) | (MTR_ROWS_AS_STORED if as_stored else 0)
+        check(lib().mtr_multi_index_load_rows(self._h, int(row_start), rows.ctypes.data_as(C.c_void_p), rows.shape[0], code))
+
+    def info(self):
+        if self._info is None:
+            n = _i64()
+            d, dt, nm, nb, ex = _i32(), _i32(), _i32(), _i32(), _i32()
+            check(lib().mtr_multi_index_info(self._h, C.byref(n), C.byref(d), C.byref(dt), C.byref(nm), C.byref(nb),
+                                             C.byref(ex)))
+            blocks = []
+            for i in range(nb.value):
+                dev, lo, hi = _i32(), _i64(), _i64()
+                check(lib().mtr_multi_index_block(self._h, i, None, C.byref(dev), C.byref(lo), C.byref(hi)))
+                blocks.append({"device": dev.value, "rows": (lo.value, hi.value)})
+            self._info = {"n": n.value, "d": d.value, "store_dtype": "bf16" if dt.value == MTR_BF16 else "fp32",
+                          "normalized": bool(nm.value), "device": blocks[0]["device"], "row_offset": 0,
+                          "blocks": blocks, "exchange": {v: k for k, v in EXCHANGES.items()}[ex.value]}
+        return self._info
+
+    @property
+    def device(self):
+        return self.info()["device"]
+
+    @property
+    def n(self):
+        return self.info()["n"]
+
+    @property
+    def d(self):
+        return self.info()["d"]
+
+    def search(self, queries, k=10, metric="cosine"):
+        """Host in, host out: (idx int64 (B, k), score float32 (B, k))."""
+        q = as_host_matrix(queries, "queries")
+        if q.shape[1] != self.d:
+            raise ValueError(f"queries have {q.shape[1]} columns, the index has {self.d}")
+        b = q.shape[0]
+        idx = np.empty((b, k), dtype=np.int64)
+        score = np.empty((b, k), dtype=np.float32)
+        check(lib().mtr_multi_index_search(self._h, q.ctypes.data_as(C.c_void_p), np_dtype_code(q), b, int(k),
+                                           METRICS[metric], idx.ctypes.data_as(C.c_void_p),
+                                           score.ctypes.data_as(C.c_void_p)))
+        return idx, score
+
+    def search_device(self, queries, k=10, metric="cosine", out=None, stream=None):
+        """Device in, device out on the first device of the list, enqueued behind
+        `stream` (default: torch's current stream there) without synchronising."""
+        import torch
+        if queries.dim() == 1:
+            queries = queries[None, :]
+        if not queries.is_cuda or not queries.is_contiguous() or queries.shape[1] != self.d:
+            raise ValueError("search_device wants a contiguous (B, d) tensor on the GPU")
+        if queries.device.index != self.device:
+            raise ValueError(f"queries are on {queries.device}, the index takes them on GPU {self.device}")
+        b = queries.shape[0]
+        if out is None:
+            idx = torch.empty((b, k), dtype=torch.int64, device=queries.device)
+            score = torch.empty((b, k), dtype=torch.float32, device=queries.device)
+        else:
+            idx, score = out
+            for t, dt in ((idx, torch.int64), (score, torch.float32)):
+                if t.device != queries.device or t.dtype != dt or t.numel() != b * k or not t.is_contiguous():
+                    raise ValueError("out must be contiguous (B, k) int64 / float32 tensors on the index's first GPU")
+        if stream is None:
+            stream = torch.cuda.current_stream(queries.device).cuda_stream
+        check(lib().mtr_multi_index_search_device(self._h, C.c_void_p(queries.data_ptr()), torch_dtype_code(queries), b,
+                                                  int(k), METRICS[metric], C.c_void_p(idx.data_ptr()),
+                                                  C.c_void_p(score.data_ptr()), C.c_void_p(stream)))
+        return idx, score
+
+    def nonfinite(self) -> bool:
+        flag = _i32()
+        check(lib().mtr_multi_index_nonfinite(self._h, C.byref(flag)))
+        return bool(flag.value)
+
+    def read_rows(self, row_start=0, n_rows=None):
+        inf = self.info()
+        if n_rows is None:
+            n_rows = inf["n"] - row_start
+        out = np.empty((n_rows, inf["d"]), dtype=np.float32)
+        check(lib().mtr_multi_index_read_rows(self._h, int(row_start), int(n_rows), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def read_rows_bf16(self, row_start=0, n_rows=None, chunk_rows=65536):
+        inf = self.info()
+        if inf["store_dtype"] != "bf16":
+            raise ValueError("read_rows_bf16 needs a bf16 index")
+        if n_rows is None:
+            n_rows = inf["n"] - row_start
+        out = np.empty((n_rows, inf["d"]), dtype=np.uint16)
+        for r0 in range(0, n_rows, chunk_rows):
+            part = self.read_rows(row_start + r0, min(chunk_rows, n_rows - r0))
+            out[r0:r0 + len(part)] = (part.view(np.uint32) >> 16).astype(np.uint16)
+        return out
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            lib().mtr_multi_index_destroy(self._h)
         self._h = None
 
     def __del__(self):

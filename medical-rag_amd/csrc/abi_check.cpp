@@ -128,6 +128,24 @@ int main() {
     EXPECT(mtr_sharded_search_device(nullptr, nullptr, nullptr, 0, 1, 1, 0, nullptr, nullptr, nullptr) == MTR_ERR_INVALID);
     mtr_comm_destroy(nullptr);
     mtr_index_destroy(nullptr);
+    // one index over several GPUs, driven by this process
+    mtr_multi_index_t* mi = nullptr;
+    const int32_t devs[3] = {0, 0, 0}, bad_devs[2] = {0, -1};
+    EXPECT(mtr_multi_index_alloc(10, 8, MTR_F32, 1, devs, 3, MTR_EXCHANGE_COPY, nullptr) == MTR_ERR_INVALID);
+    EXPECT(mtr_multi_index_alloc(10, 8, MTR_F32, 1, nullptr, 3, MTR_EXCHANGE_COPY, &mi) == MTR_ERR_INVALID && mi == nullptr);
+    EXPECT(mtr_multi_index_alloc(10, 8, MTR_F32, 1, devs, 0, MTR_EXCHANGE_COPY, &mi) == MTR_ERR_INVALID);
+    EXPECT(mtr_multi_index_alloc(10, 8, MTR_F32, 1, devs, 65, MTR_EXCHANGE_COPY, &mi) == MTR_ERR_INVALID);
+    EXPECT(mtr_multi_index_alloc(0, 8, MTR_F32, 1, devs, 3, MTR_EXCHANGE_COPY, &mi) == MTR_ERR_INVALID);
+    EXPECT(mtr_multi_index_alloc(10, 8, MTR_F32, 1, devs, 3, 9, &mi) == MTR_ERR_INVALID);
+    EXPECT(mtr_multi_index_alloc(10, 8, MTR_F32, 1, bad_devs, 2, MTR_EXCHANGE_COPY, &mi) != MTR_OK && mi == nullptr);
+    EXPECT(mtr_multi_index_load_rows(nullptr, 0, nullptr, 0, MTR_F32) == MTR_ERR_INVALID);
+    EXPECT(mtr_multi_index_search(nullptr, nullptr, 0, 1, 1, 0, nullptr, nullptr) == MTR_ERR_INVALID);
+    EXPECT(mtr_multi_index_search_device(nullptr, nullptr, 0, 1, 1, 0, nullptr, nullptr, nullptr) == MTR_ERR_INVALID);
+    EXPECT(mtr_multi_index_nonfinite(nullptr, nullptr) == MTR_ERR_INVALID);
+    EXPECT(mtr_multi_index_info(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr) == MTR_ERR_INVALID);
+    EXPECT(mtr_multi_index_block(nullptr, 0, nullptr, nullptr, nullptr, nullptr) == MTR_ERR_INVALID);
+    EXPECT(mtr_multi_index_read_rows(nullptr, 0, 0, nullptr) == MTR_ERR_INVALID);
+    mtr_multi_index_destroy(nullptr);
     int32_t v = -7;
     EXPECT(mtr_tuning_get("wide_min_batch", &v) == MTR_OK && v == 129);
     EXPECT(mtr_tuning_set("wide_min_batch", 200) == MTR_OK && mtr_tuning_get("wide_min_batch", &v) == MTR_OK && v == 200);
@@ -157,6 +175,35 @@ int main() {
         q[3] = 1.0f / 0.0f;
         EXPECT(mtr_index_search(ix, q.data(), MTR_F32, 0, b, k, MTR_COSINE, idx.data(), score.data()) == MTR_ERR_NONFINITE);
         mtr_index_destroy(ix);
+        // the same rows as three blocks on this GPU (100 rows each), and as five blocks of 2 rows: one stays empty
+        q[3] = rows[(size_t)5 * d + 3];
+        for (int blocks : {3, 5}) {
+            const int32_t five[5] = {0, 0, 0, 0, 0};
+            const int64_t rows_here = blocks == 3 ? n : 4;
+            EXPECT(mtr_multi_index_create(rows.data(), rows_here, d, MTR_F32, MTR_F32, 1, five, blocks, MTR_EXCHANGE_AUTO, &mi) == MTR_OK);
+            if (!mi) break;
+            int32_t n_blocks = 0, form = -1, dev = -1;
+            int64_t lo = -1, hi = -1;
+            mtr_index_t* blk = nullptr;
+            EXPECT(mtr_multi_index_info(mi, nullptr, nullptr, nullptr, nullptr, &n_blocks, &form) == MTR_OK && n_blocks == blocks &&
+                   form == MTR_EXCHANGE_COPY);
+            EXPECT(mtr_multi_index_block(mi, blocks - 1, &blk, &dev, &lo, &hi) == MTR_OK && dev == 0 && hi == rows_here &&
+                   (blocks == 3 ? (lo == 200 && blk != nullptr) : (lo == 4 && blk == nullptr)));
+            EXPECT(mtr_multi_index_block(mi, blocks, nullptr, nullptr, nullptr, nullptr) == MTR_ERR_INVALID);
+            EXPECT(mtr_multi_index_search(mi, q.data(), MTR_F32, b, k, MTR_COSINE, idx.data(), score.data()) == MTR_OK);
+            if (blocks == 3)
+                for (int j = 0; j < b; ++j) EXPECT(idx[(size_t)j * k] == 17 * j + 5);
+            else
+                EXPECT(idx[4] == -1 && idx[3] >= 0);   // four rows, five result slots
+            EXPECT(mtr_multi_index_read_rows(mi, rows_here - 2, 2, back.data()) == MTR_OK);
+            EXPECT(mtr_multi_index_read_rows(mi, rows_here - 1, 2, back.data()) == MTR_ERR_INVALID);
+            EXPECT(mtr_multi_index_load_rows(mi, rows_here - 1, rows.data(), 2, MTR_F32) == MTR_ERR_INVALID);
+            q[3] = 0.0f / 0.0f;
+            EXPECT(mtr_multi_index_search(mi, q.data(), MTR_F32, b, k, MTR_COSINE, idx.data(), score.data()) == MTR_ERR_NONFINITE);
+            q[3] = rows[(size_t)5 * d + 3];
+            mtr_multi_index_destroy(mi);
+            mi = nullptr;
+        }
         printf("abi_check: GPU path exercised\n");
     } else {
         EXPECT(ix == nullptr && strlen(mtr_last_error()) > 0);

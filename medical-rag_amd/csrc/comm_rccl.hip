@@ -19,9 +19,11 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <string>
 
 #include "../../include/medtutor_retrieval.h"
 #include "mtr_device.h"
+#include "rccl_loader.h"
 
 namespace mtr {
 int set_error(int code, const char* fmt, ...);  // mtr_api.hip: thread-local message behind mtr_last_error()
@@ -37,15 +39,9 @@ namespace {
                                   hipGetErrorString(e_));                                                    \
     } while (0)
 
-struct Rccl {
-    void* handle = nullptr;
-    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
-    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
-    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
-    const char* (*GetErrorString)(ncclResult_t) = nullptr;
-    char why[256] = "";
-};
+}  // namespace
+
+namespace mtr {
 
 // The library, resolved once.  An RCCL that the process already has mapped
 // (PyTorch ships one) is preferred over loading a second copy.
@@ -79,11 +75,23 @@ const Rccl* rccl() {
         if (!v.GetUniqueId || !v.CommInitRank || !v.CommDestroy || !v.AllGather || !v.GetErrorString) {
             snprintf(v.why, sizeof(v.why), "the loaded RCCL lacks a needed entry point");
             v.handle = nullptr;
+            return v;
         }
+        // one process driving several GPUs (multi_index.hip); absent from a library: that form is unavailable
+        v.CommInitAll = reinterpret_cast<decltype(v.CommInitAll)>(dlsym(v.handle, "ncclCommInitAll"));
+        v.GroupStart = reinterpret_cast<decltype(v.GroupStart)>(dlsym(v.handle, "ncclGroupStart"));
+        v.GroupEnd = reinterpret_cast<decltype(v.GroupEnd)>(dlsym(v.handle, "ncclGroupEnd"));
         return v;
     }();
     return &r;
 }
+
+}  // namespace mtr
+
+namespace {
+
+using mtr::Rccl;
+using mtr::rccl;
 
 #define RCCL_TRY(r, expr)                                                                              \
     do {                                                                                               \
@@ -124,6 +132,10 @@ struct mtr_comm {
         bool used = false;
     } slots[kSlots];
     int next = 0;
+    // Set when this rank could not take part in a collective its peers have
+    // entered (no memory for the exchange buffers): the ranks' sequences of
+    // all-gathers no longer match, so every later call fails at once.
+    bool poisoned = false;
 };
 
 namespace {
@@ -131,7 +143,7 @@ namespace {
 size_t block_words(int b, int k) { return (size_t)b * k + ((size_t)b * k + 1) / 2; }
 
 // The next buffer set, large enough for (b, k), safe to overwrite from `stream`.
-int take_slot(mtr_comm* c, int b, int k, hipStream_t stream, mtr_comm::Slot** out) {
+int take_slot_unguarded(mtr_comm* c, int b, int k, hipStream_t stream, mtr_comm::Slot** out) {
     mtr_comm::Slot& s = c->slots[c->next];
     c->next = (c->next + 1) % kSlots;
     const size_t words = block_words(b, k);
@@ -149,6 +161,17 @@ int take_slot(mtr_comm* c, int b, int k, hipStream_t stream, mtr_comm::Slot** ou
     if (!s.done) HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
     *out = &s;
     return MTR_OK;
+}
+
+// Without buffers this rank cannot enter the all-gather the other ranks are
+// about to enter: the communicator is of no use from here on.
+int take_slot(mtr_comm* c, int b, int k, hipStream_t stream, mtr_comm::Slot** out) {
+    if (c->poisoned)
+        return mtr::set_error(MTR_ERR_COMM, "the communicator missed a collective after an earlier failure on this rank: "
+                                            "destroy it on every rank");
+    const int rc = take_slot_unguarded(c, b, k, stream, out);
+    if (rc != MTR_OK) c->poisoned = true;
+    return rc;
 }
 
 // All-gather of the slot's send block and the merge of every rank's block.
@@ -258,10 +281,14 @@ int mtr_comm_exchange_merge_device(mtr_comm_t* c, const int64_t* dev_local_idx, 
     mtr_comm::Slot* slot = nullptr;
     if ((rc = take_slot(c, b, k_in, s, &slot)) != MTR_OK) return rc;
     const size_t cells = (size_t)b * k_in;
-    if (dev_local_idx) {
+    auto stage = [&]() -> int {
+        if (!dev_local_idx) return fill_padding(slot, b, k_in, s);
         HIP_TRY(hipMemcpyAsync(slot->send, dev_local_idx, cells * 8, hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipMemcpyAsync(slot->send + cells, dev_local_score, cells * 4, hipMemcpyDeviceToDevice, s));
-    } else if ((rc = fill_padding(slot, b, k_in, s)) != MTR_OK) {
+        return MTR_OK;
+    };
+    if ((rc = stage()) != MTR_OK) {
+        c->poisoned = true;   // this rank stays out of an all-gather its peers enter
         return rc;
     }
     return exchange_and_merge(c, slot, b, k_in, k_out, reinterpret_cast<long long*>(dev_out_idx), dev_out_score, s);
@@ -277,19 +304,33 @@ int mtr_sharded_search_device(mtr_index_t* index, mtr_comm_t* c, const void* dev
     mtr_comm::Slot* slot = nullptr;
     if ((rc = take_slot(c, b, k, s, &slot)) != MTR_OK) return rc;
     const size_t cells = (size_t)b * k;
+    // A failure of this rank's own search must not keep it out of the all-gather
+    // that the other ranks have entered or will enter: it then contributes a block
+    // of padding, runs the exchange and the merge like everybody else, and
+    // returns its error afterwards.
+    int local_rc = MTR_OK;
+    std::string local_msg;
     if (index) {
         int32_t dev = -1;
-        if ((rc = mtr_index_info(index, nullptr, nullptr, nullptr, nullptr, &dev, nullptr)) != MTR_OK) return rc;
-        if (dev != c->device)
-            return mtr::set_error(MTR_ERR_INVALID, "the shard is on GPU %d, the communicator on GPU %d", dev, c->device);
+        local_rc = mtr_index_info(index, nullptr, nullptr, nullptr, nullptr, &dev, nullptr);
+        if (local_rc == MTR_OK && dev != c->device)
+            local_rc = mtr::set_error(MTR_ERR_INVALID, "the shard is on GPU %d, the communicator on GPU %d", dev, c->device);
         // the local top-k goes straight into the send block
-        rc = mtr_index_search_device(index, dev_queries, q_dtype, b, k, metric, reinterpret_cast<int64_t*>(slot->send),
-                                     reinterpret_cast<float*>(slot->send + cells), stream);
-        if (rc != MTR_OK) return rc;
-    } else if ((rc = fill_padding(slot, b, k, s)) != MTR_OK) {   // a rank without rows still takes part
-        return rc;
+        if (local_rc == MTR_OK)
+            local_rc = mtr_index_search_device(index, dev_queries, q_dtype, b, k, metric,
+                                               reinterpret_cast<int64_t*>(slot->send),
+                                               reinterpret_cast<float*>(slot->send + cells), stream);
+        if (local_rc != MTR_OK) local_msg = mtr_last_error();
     }
-    return exchange_and_merge(c, slot, b, k, k, reinterpret_cast<long long*>(dev_out_idx), dev_out_score, s);
+    if (!index || local_rc != MTR_OK) {   // a rank without rows (or without a result) still takes part
+        if ((rc = fill_padding(slot, b, k, s)) != MTR_OK) {
+            c->poisoned = true;
+            return rc;
+        }
+    }
+    rc = exchange_and_merge(c, slot, b, k, k, reinterpret_cast<long long*>(dev_out_idx), dev_out_score, s);
+    if (local_rc != MTR_OK) return mtr::set_error(local_rc, "%s", local_msg.c_str());
+    return rc;
 }
 
 }  // extern "C"

@@ -158,6 +158,11 @@ struct mtr_index {
     int* flag = nullptr;  // device word that kernels raise to the call's epoch on NaN/inf (mtr::NonfiniteFlag)
     int epoch = 0;        // last value handed out; the word never needs clearing
     int device_epoch = 0; // ... and the one of the last search enqueued without waiting
+    // The allocation-free entry point may run under stream capture, where a value
+    // passed to a kernel is frozen into the graph: it uses the block's second
+    // word instead, cleared by a (captured) fill kernel at the start of every call
+    // and raised to 1, so that every replay reports its own queries.
+    bool last_device_noalloc = false;
     hipStream_t stream = nullptr;
     std::mutex mu;
     DevBuf scratch[kScratchSlots];  // grown on demand, kept between searches
@@ -424,19 +429,26 @@ int enqueue_mfma(mtr_index* ix, S& sc, const mtr::MfmaPlan& plan, const void* de
     return MTR_OK;
 }
 
-// Scoring + merge of one batch, enqueued on `stream`.  dev_queries: b x d in
-// q_dtype on the shard's device.
-template <typename S>
-int enqueue_search(mtr_index* ix, S& sc, const void* dev_queries, int q_dtype, int b, int k, int metric,
-                   long long* dev_out_idx, float* dev_out_score, hipStream_t stream, int* epoch_out = nullptr) {
-    // this search's value of the non-finite word (see mtr::NonfiniteFlag)
-    if (ix->epoch == 0x7fffffff) {   // once in two billion searches: start over
+// The next value of the handle's non-finite word (see mtr::NonfiniteFlag).  Once
+// in two billion calls the word starts over: everything enqueued on the handle
+// is waited for first (never reached by the allocation-free entry point, which
+// does not use epochs).
+int next_epoch(mtr_index* ix, hipStream_t stream, mtr::NonfiniteFlag* nf) {
+    if (ix->epoch == 0x7fffffff) {
+        if (ix->used) HIP_TRY(hipEventSynchronize(ix->last_use));
         HIP_TRY(hipStreamSynchronize(stream));
         HIP_TRY(hipMemset(ix->flag, 0, 4));
         ix->epoch = 0;
     }
-    const mtr::NonfiniteFlag nf{ix->flag, ++ix->epoch};
-    if (epoch_out) *epoch_out = nf.value;
+    *nf = mtr::NonfiniteFlag{ix->flag, ++ix->epoch};
+    return MTR_OK;
+}
+
+// Scoring + merge of one batch, enqueued on `stream`.  dev_queries: b x d in
+// q_dtype on the shard's device.
+template <typename S>
+int enqueue_search(mtr_index* ix, S& sc, const void* dev_queries, int q_dtype, int b, int k, int metric,
+                   mtr::NonfiniteFlag nf, long long* dev_out_idx, float* dev_out_score, hipStream_t stream) {
     if (metric == MTR_COSINE && !ix->normalized)
         return fail(MTR_ERR_INVALID, "cosine search needs a shard built with normalize=1");
     if (b >= mfma_min_batch(ix->dtype)) {
@@ -553,14 +565,10 @@ int mtr_index_alloc(int64_t n, int32_t d, int32_t store_dtype, int32_t normalize
         mtr_index_destroy(ix);
         return fail(MTR_ERR_HIP, "shard set-up: %s", hipGetErrorString(e));
     }
-    // the shard's GPU is current (guard): its address of the static scratch array
-    int rc = static_scratch_for(device_id, &ix->static_scratch);
-    if (rc != MTR_OK) {
-        std::string keep = g_err;
-        mtr_index_destroy(ix);
-        g_err = keep;
-        return rc;
-    }
+    // The shard's GPU is current (guard): its address of the static scratch array.
+    // Only the allocation-free entry point needs it, so a failed lookup does not
+    // fail the shard: that entry point then reports the array as unresolved.
+    if (static_scratch_for(device_id, &ix->static_scratch) != MTR_OK) ix->static_scratch = nullptr;
     *out = ix;
     return MTR_OK;
 }
@@ -622,7 +630,8 @@ int mtr_index_load_rows(mtr_index_t* ix, int64_t row_start, const void* rows, in
     std::lock_guard<std::mutex> lock(ix->mu);
     DeviceGuard guard(ix->device);
     if ((rc = begin_use(ix, ix->stream)) != MTR_OK) return rc;
-    const mtr::NonfiniteFlag nf{ix->flag, ++ix->epoch};
+    mtr::NonfiniteFlag nf;
+    if ((rc = next_epoch(ix, ix->stream, &nf)) != MTR_OK) return rc;
     if (n_rows == 0) {
         // nothing to convert
     } else if (rows_on_device) {
@@ -672,9 +681,11 @@ int mtr_index_search(mtr_index_t* ix, const void* queries, int32_t q_dtype, int3
     if ((rc = ix->out_s.reserve((size_t)b * k * 4)) != MTR_OK) return rc;
     Scratch sc;
     sc.ix = ix;
-    int epoch = 0;
-    rc = enqueue_search(ix, sc, dq, q_dtype, b, k, metric, static_cast<long long*>(ix->out_i.p),
-                        static_cast<float*>(ix->out_s.p), ix->stream, &epoch);
+    mtr::NonfiniteFlag nf;
+    if ((rc = next_epoch(ix, ix->stream, &nf)) != MTR_OK) return rc;
+    const int epoch = nf.value;
+    rc = enqueue_search(ix, sc, dq, q_dtype, b, k, metric, nf, static_cast<long long*>(ix->out_i.p),
+                        static_cast<float*>(ix->out_s.p), ix->stream);
     if (rc != MTR_OK) {
         std::string keep = g_err;
         (void)hipStreamSynchronize(ix->stream);
@@ -704,8 +715,12 @@ int mtr_index_search_device(mtr_index_t* ix, const void* dev_queries, int32_t q_
     if ((rc = begin_use(ix, s)) != MTR_OK) return rc;
     Scratch sc;
     sc.ix = ix;
-    rc = enqueue_search(ix, sc, dev_queries, q_dtype, b, k, metric, reinterpret_cast<long long*>(dev_out_idx),
-                        dev_out_score, s, &ix->device_epoch);
+    mtr::NonfiniteFlag nf;
+    if ((rc = next_epoch(ix, s, &nf)) != MTR_OK) return rc;
+    ix->device_epoch = nf.value;
+    ix->last_device_noalloc = false;
+    rc = enqueue_search(ix, sc, dev_queries, q_dtype, b, k, metric, nf, reinterpret_cast<long long*>(dev_out_idx),
+                        dev_out_score, s);
     std::string keep = g_err;
     const int rc2 = end_use(ix, s);
     if (rc != MTR_OK) g_err = keep;
@@ -723,8 +738,14 @@ int mtr_index_search_device_noalloc(mtr_index_t* ix, const void* dev_queries, in
     // stream capture, and its callers keep to one stream per GPU.
     StaticScratch sc;
     sc.ix = ix;
-    return enqueue_search(ix, sc, dev_queries, q_dtype, b, k, metric, reinterpret_cast<long long*>(dev_out_idx),
-                          dev_out_score, static_cast<hipStream_t>(stream), &ix->device_epoch);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // The non-finite report of this entry point: word 1 of the handle's flag
+    // block, cleared here (a kernel, so a captured call clears it on every
+    // replay) and raised to 1 by the kernels; no epoch, which capture would freeze.
+    HIP_TRY(mtr::launch_fill_u32(ix->flag + 1, 0u, 1, s));
+    ix->last_device_noalloc = true;
+    return enqueue_search(ix, sc, dev_queries, q_dtype, b, k, metric, mtr::NonfiniteFlag{ix->flag + 1, 1},
+                          reinterpret_cast<long long*>(dev_out_idx), dev_out_score, s);
 }
 
 int mtr_index_nonfinite(mtr_index_t* ix, int32_t* nonfinite) {
@@ -734,9 +755,10 @@ int mtr_index_nonfinite(mtr_index_t* ix, int32_t* nonfinite) {
     std::lock_guard<std::mutex> lock(ix->mu);
     DeviceGuard guard(ix->device);
     if (ix->used) HIP_TRY(hipEventSynchronize(ix->last_use));
-    int flag = 0;
-    HIP_TRY(hipMemcpy(&flag, ix->flag, 4, hipMemcpyDeviceToHost));
-    *nonfinite = (ix->device_epoch > 0 && flag == ix->device_epoch) ? 1 : 0;
+    int flag[2] = {0, 0};
+    HIP_TRY(hipMemcpy(flag, ix->flag, 8, hipMemcpyDeviceToHost));
+    if (ix->last_device_noalloc) *nonfinite = flag[1] != 0 ? 1 : 0;
+    else *nonfinite = (ix->device_epoch > 0 && flag[0] == ix->device_epoch) ? 1 : 0;
     return MTR_OK;
 }
 

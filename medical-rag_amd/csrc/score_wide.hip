@@ -400,7 +400,8 @@ __global__ __launch_bounds__(kWideThreads, 2) void score_filter_wide_kernel(Wide
                             // tells the selection kernel that the list is incomplete.
                             const int r0 = (g >> 2) * 16 + (g & 3), r1 = ((g + 1) >> 2) * 16 + ((g + 1) & 3),
                                       r2 = ((g + 2) >> 2) * 16 + ((g + 2) & 3);
-                            const bool h0 = v0 >= thr[nn], h1 = v1 >= thr[nn], h2 = v2 >= thr[nn];
+                            // (the last group holds two scores: its padding must not pass a floor of -inf)
+                            const bool h0 = v0 >= thr[nn], h1 = g + 1 < 32 && v1 >= thr[nn], h2 = g + 2 < 32 && v2 >= thr[nn];
                             const float vs = h0 ? v0 : h1 ? v1 : v2;
                             const int rs = h0 ? r0 : h1 ? r1 : r2;
                             *reinterpret_cast<u32x2*>(qkeys + (cnt[nn] & cap_mask)) =

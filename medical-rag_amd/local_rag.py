@@ -31,21 +31,39 @@ from . import _native, index_format
 __all__ = ["PageIndex", "load_embeddings", "embed_queries", "embed_queries_device", "retrieve_top_index",
            "get_surrounding_pages", "search", "configure", "configure_from_config", "invalidate"]
 
+def _device_list(value) -> list:
+    """GPU ordinals from an int, a list of ints or a string like "0,1,2"."""
+    if isinstance(value, str):
+        value = [part for part in value.replace(";", ",").split(",") if part.strip()]
+    if isinstance(value, (list, tuple)):
+        devices = [int(v) for v in value]
+    else:
+        devices = [int(value)]
+    if not devices or any(dev < 0 for dev in devices):
+        raise ValueError("the retriever needs at least one GPU ordinal, none negative")
+    return devices
+
+
 _SETTINGS = {
-    "device": int(os.environ.get("MEDTUTOR_RETRIEVAL_DEVICE", os.environ.get("LOCAL_RANK", "0")) or 0),
+    # one GPU, or several: the index is then cut into row blocks, one per entry
+    "devices": _device_list(os.environ.get("MEDTUTOR_RETRIEVAL_DEVICE", os.environ.get("LOCAL_RANK", "0")) or 0),
     "store_dtype": os.environ.get("MEDTUTOR_RETRIEVAL_DTYPE", "fp32"),
     "top_k": 1,     # the reference keeps one page per keyword (np.argmax, local_rag.py:78)
     "window": 1,    # ... and its two neighbours (get_surrounding_pages' default)
 }
 
 
-def configure(device: int | None = None, store_dtype: str | None = None, top_k: int | None = None,
-              window: int | None = None) -> dict:
-    """Sets the GPU and storage type ("fp32" or "bf16") used for indexes built
-    after this call, and the batched caller's hits per keyword / page window.
-    Defaults keep the reference's behaviour: fp32 on GPU 0, one hit, window 1."""
-    if device is not None:
-        _SETTINGS["device"] = int(device)
+def configure(device=None, store_dtype: str | None = None, top_k: int | None = None,
+              window: int | None = None, devices=None) -> dict:
+    """Sets the GPU -- or the list of GPUs the rows are spread over, in
+    contiguous blocks, all driven by this one process -- and the storage type
+    ("fp32" or "bf16") used for indexes built after this call, and the batched
+    caller's hits per keyword / page window.  Defaults keep the reference's
+    behaviour: fp32 on GPU 0, one hit, window 1.  Returns the settings in force
+    (`devices`: the list; `device`: its first entry), a dict that configure(**it)
+    takes back."""
+    if devices is not None or device is not None:
+        _SETTINGS["devices"] = _device_list(devices if devices is not None else device)
     if store_dtype is not None:
         if store_dtype not in _native.STORE_DTYPES:
             raise ValueError(f"store_dtype must be one of {sorted(_native.STORE_DTYPES)}")
@@ -58,7 +76,7 @@ def configure(device: int | None = None, store_dtype: str | None = None, top_k: 
         if int(window) < 0:
             raise ValueError("window must not be negative")
         _SETTINGS["window"] = int(window)
-    return dict(_SETTINGS)
+    return dict(_SETTINGS, device=_SETTINGS["devices"][0])
 
 
 def configure_from_config(config: dict) -> dict:
@@ -67,15 +85,16 @@ def configure_from_config(config: dict) -> dict:
     `hf_embedding_model` and `embedding_model_device` from.  None of them exists
     in the reference, and leaving them out keeps its behaviour:
         local_index_dtype       "fp32" (default) | "bf16"
-        local_retriever_devices GPU ordinal, or a list of them (the first is used
-                                by this single-process retriever; the vLLM workers
-                                pin their own GPUs, async_main.py:39)
+        local_retriever_devices GPU ordinal, or a list of them: the index is then
+                                row-sharded over all of them and searched from
+                                this one process (the vLLM workers pin their own
+                                GPUs, async_main.py:39)
         local_top_k             hits per keyword for the batched caller (default 1)
         local_window            neighbouring pages on each side (default 1)
     Unknown or absent keys are ignored; bad values raise ValueError."""
     devices = config.get("local_retriever_devices")
-    if isinstance(devices, (list, tuple)):
-        devices = devices[0] if devices else None
+    if isinstance(devices, (list, tuple)) and not devices:
+        devices = None
     return configure(device=devices, store_dtype=config.get("local_index_dtype"), top_k=config.get("local_top_k"),
                      window=config.get("local_window"))
 
@@ -94,7 +113,7 @@ class PageIndex(Sequence):
         self._shard = shard
 
     @classmethod
-    def from_pages(cls, pages: list, device: int | None = None, store_dtype: str | None = None):
+    def from_pages(cls, pages: list, device=None, store_dtype: str | None = None):
         """pages: list of dicts with an "embedding" list each (the schema
         written at pipeline/utils/embed.py:74-79)."""
         if not pages:
@@ -106,10 +125,23 @@ class PageIndex(Sequence):
         return cls.from_matrix(mat, meta, device=device, store_dtype=store_dtype)
 
     @classmethod
-    def from_matrix(cls, matrix, pages_meta: list | None = None, device: int | None = None,
+    def from_matrix(cls, matrix, pages_meta: list | None = None, device=None,
                     store_dtype: str | None = None, normalize: bool = True, as_stored: bool = False):
         """matrix: (n, d) floats, or uint16 bfloat16 bits (a bf16 index file).
-        as_stored: rows read back from a shard, not to be normalised again."""
+        as_stored: rows read back from a shard, not to be normalised again.
+        device: one GPU ordinal, or a list of them (default: what configure set):
+        with several the rows are cut into contiguous blocks, one per GPU."""
+        devices = _SETTINGS["devices"] if device is None else _device_list(device)
+        if len(devices) > 1:
+            if not (isinstance(matrix, np.ndarray) and matrix.ndim == 2):
+                matrix = _native.as_host_matrix(matrix, "rows")
+            if pages_meta is None:
+                pages_meta = [{"index": i, "text": ""} for i in range(matrix.shape[0])]
+            if len(pages_meta) != matrix.shape[0]:
+                raise ValueError("one page dict per matrix row is required")
+            shard = _native.MultiShard.from_host(matrix, devices, store_dtype=store_dtype or _SETTINGS["store_dtype"],
+                                                 normalize=normalize, as_stored=as_stored)
+            return cls(pages_meta, shard)
         matrix = _native.as_host_matrix(matrix, "rows")
         if pages_meta is None:
             pages_meta = [{"index": i, "text": ""} for i in range(matrix.shape[0])]
@@ -117,19 +149,21 @@ class PageIndex(Sequence):
             raise ValueError("one page dict per matrix row is required")
         shard = _native.DeviceShard.from_host(
             matrix, store_dtype=store_dtype or _SETTINGS["store_dtype"], normalize=normalize,
-            device=_SETTINGS["device"] if device is None else device, as_stored=as_stored)
+            device=devices[0], as_stored=as_stored)
         return cls(pages_meta, shard)
 
     def save_sidecar(self, json_path: str, bind_to_source: bool = True):
         """Writes the binary sidecar of json_path from this index's shard: a bf16
         shard gives a bf16 file holding exactly its stored rows (half the bytes
         of the fp32 form on disk and over PCIe; loading it reproduces the shard
-        bit for bit), an fp32 shard the fp32 form."""
-        if self._shard.info()["store_dtype"] == "bf16":
-            return index_format.write_sidecar(json_path, self._shard.read_rows_bf16(), self._pages,
-                                              bind_to_source=bind_to_source, as_stored=True)
-        return index_format.write_sidecar(json_path, self._shard.read_rows(), self._pages,
-                                          bind_to_source=bind_to_source, as_stored=True)
+        bit for bit), an fp32 shard the fp32 form.  Only a normalised shard's rows
+        are marked "as stored" (loaded without a second normalisation): the rows of
+        a shard built with normalize=False are written as they are and normalised
+        when load_embeddings reads them, as every index is."""
+        info = self._shard.info()
+        rows = self._shard.read_rows_bf16() if info["store_dtype"] == "bf16" else self._shard.read_rows()
+        return index_format.write_sidecar(json_path, rows, self._pages, bind_to_source=bind_to_source,
+                                          as_stored=bool(info["normalized"]))
 
     # -- Sequence protocol ----------------------------------------------------
     def __len__(self):
@@ -166,28 +200,42 @@ class PageIndex(Sequence):
 
 
 # Plain page lists handed to retrieve_top_index are uploaded once and reused
-# while they are the same list with the same vectors in it; at most
-# _UPLOADED_MAX such uploads are kept.
+# while they are the same list with the same vectors in it (_fingerprint looks
+# at every page on every call); at most _UPLOADED_MAX such uploads are kept.
 _UPLOADED: dict = {}
 _UPLOADED_MAX = 2
 _UPLOADED_LOCK = threading.Lock()
 
 
+_FULL_VALUE_MARKS = 16384   # page lists up to this long have two values of EVERY vector in their mark
+
+
 def _fingerprint(pages) -> tuple:
-    """Cheap identity of a page container's contents: its length and, for up to
-    64 evenly spaced pages, the identity of the vector object and two of its
-    values.  Replacing or editing a sampled vector, or changing the length,
-    changes it (the reference rebuilds its matrix on every call,
-    pipeline/utils/local_rag.py:76; an edit this sample misses needs invalidate())."""
+    """Identity of a page container's contents, cheap beside a search.  The
+    reference rebuilds its matrix on every call
+    (pipeline/utils/local_rag.py:76), so any change to the list shows in its next
+    answer; here a list is uploaded once and reused while its mark is unchanged.
+    The mark covers EVERY page: the identity and length of each vector object,
+    and its first and last value (for lists beyond _FULL_VALUE_MARKS pages the
+    values of 4096 evenly spaced ones).  Replacing any page's vector, changing
+    the number of pages or a vector's length, or rescaling vectors in place
+    changes it; an edit of single inner elements of a vector object does not and
+    needs invalidate().  A numpy matrix is marked by a checksum of all its bytes."""
     n = len(pages)
     if isinstance(pages, np.ndarray):
-        probe = pages[:: max(1, n // 64)]
-        return (n, pages.shape, float(probe.sum()))
-    marks = []
-    for i in range(0, n, max(1, n // 64)):
-        vec = pages[i]["embedding"] if isinstance(pages[i], dict) else pages[i]
-        marks.append((id(vec), len(vec), float(vec[0]) if len(vec) else 0.0, float(vec[-1]) if len(vec) else 0.0))
-    return (n, tuple(marks))
+        flat = np.ascontiguousarray(pages).view(np.uint8).reshape(-1)
+        try:
+            import xxhash
+            digest = xxhash.xxh3_64_intdigest(flat)
+        except ImportError:
+            import zlib
+            digest = zlib.adler32(flat)
+        return (n, pages.shape, str(pages.dtype), digest)
+    vectors = [p["embedding"] if isinstance(p, dict) else p for p in pages]
+    shape_mark = hash(tuple([(id(v), len(v)) for v in vectors]))
+    step = 1 if n <= _FULL_VALUE_MARKS else max(1, n // 4096)
+    value_mark = hash(tuple([(float(v[0]), float(v[-1])) for v in vectors[::step] if len(v)]))
+    return (n, shape_mark, value_mark)
 
 
 def invalidate(page_embeddings=None) -> None:
@@ -260,7 +308,9 @@ def load_embeddings(path: str):
         if not pages:
             return pages
         index = PageIndex.from_pages(pages)
-    logging.info(f"Loaded {len(index)} page embeddings (d={index.shard.d}) into HBM on GPU {index.shard.info()['device']}")
+    where = index.shard.info()
+    gpus = sorted({blk["device"] for blk in where["blocks"]}) if "blocks" in where else [where["device"]]
+    logging.info(f"Loaded {len(index)} page embeddings (d={index.shard.d}) into HBM on GPU {', '.join(map(str, gpus))}")
     return index
 
 

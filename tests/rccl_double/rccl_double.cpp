@@ -4,11 +4,15 @@
 // GPU, where the real RCCL refuses to put two ranks on one device.  It says
 // nothing about RCCL itself.  Never loaded unless MTR_RCCL_LIBRARY names it.
 //
-// It implements the five entry points the library resolves, for ranks that are
-// processes of one host: an all-gather is a stream synchronisation, a copy of
-// the send block to a shared-memory segment, a barrier, and copies of every
-// rank's block back to the device -- a legal (blocking, slow) implementation
-// of the same contract.
+// It implements the entry points the library resolves.  For ranks that are
+// processes of one host (ncclCommInitRank): an all-gather is a stream
+// synchronisation, a copy of the send block to a shared-memory segment, a
+// barrier, and copies of every rank's block back to the device -- a legal
+// (blocking, slow) implementation of the same contract.  For the ranks of ONE
+// process (ncclCommInitAll, any device list, repeats included): all-gathers
+// issued between ncclGroupStart and ncclGroupEnd are carried out at
+// ncclGroupEnd, once every rank of the communicator has issued its own, by
+// device copies behind a synchronisation of the ranks' streams.
 #include <fcntl.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -22,6 +26,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <random>
+#include <vector>
 
 namespace {
 
@@ -40,7 +45,36 @@ struct Double {
     Header* header = nullptr;
     char* slots = nullptr;
     size_t bytes = 0;
+    int local_group = 0;   // > 0: a rank of a communicator made by ncclCommInitAll (all ranks in this process)
 };
+
+// All-gathers of in-process ranks waiting for ncclGroupEnd.
+struct Pending {
+    Double* d;
+    const void* send;
+    void* recv;
+    size_t bytes;
+    hipStream_t stream;
+};
+thread_local int g_depth = 0;
+thread_local std::vector<Pending> g_pending;
+std::atomic<int> g_next_group{1};
+
+// Every rank of a group has issued its all-gather: synchronise their streams,
+// then copy every send block into every receive buffer.
+ncclResult_t run_local(std::vector<Pending>& ops) {
+    for (auto& op : ops)
+        if (hipStreamSynchronize(op.stream) != hipSuccess) return ncclUnhandledCudaError;
+    for (auto& dst : ops)
+        for (auto& src : ops) {
+            if (src.d->local_group != dst.d->local_group) continue;
+            if (src.bytes != dst.bytes) return ncclInvalidArgument;
+            if (hipMemcpy(static_cast<char*>(dst.recv) + src.bytes * (size_t)src.d->rank, src.send, src.bytes,
+                          hipMemcpyDefault) != hipSuccess)
+                return ncclUnhandledCudaError;
+        }
+    return ncclSuccess;
+}
 
 bool barrier(Double* d) {
     const int gen = d->header->generation.load();
@@ -113,10 +147,43 @@ ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId id, int
     return ncclSuccess;
 }
 
+ncclResult_t ncclCommInitAll(ncclComm_t* comms, int ndev, const int* devlist) {
+    if (!comms || ndev < 1) return ncclInvalidArgument;
+    (void)devlist;   // copies between the ranks' buffers go by unified addressing, whatever device holds them
+    const int group = g_next_group.fetch_add(1);
+    for (int r = 0; r < ndev; ++r) {
+        Double* d = new Double;
+        d->rank = r;
+        d->world = ndev;
+        d->local_group = group;
+        comms[r] = reinterpret_cast<ncclComm_t>(d);
+    }
+    return ncclSuccess;
+}
+
+ncclResult_t ncclGroupStart() {
+    ++g_depth;
+    return ncclSuccess;
+}
+
+ncclResult_t ncclGroupEnd() {
+    if (g_depth < 1) return ncclInvalidUsage;
+    if (--g_depth > 0) return ncclSuccess;
+    std::vector<Pending> ops;
+    ops.swap(g_pending);
+    // a group must hold the all-gather of every rank of each communicator it touches
+    for (auto& op : ops) {
+        int members = 0;
+        for (auto& other : ops) members += other.d->local_group == op.d->local_group;
+        if (members != op.d->world) return ncclInvalidUsage;
+    }
+    return run_local(ops);
+}
+
 ncclResult_t ncclCommDestroy(ncclComm_t comm) {
     Double* d = reinterpret_cast<Double*>(comm);
     if (!d) return ncclSuccess;
-    munmap(d->header, d->bytes);
+    if (!d->local_group) munmap(d->header, d->bytes);
     delete d;
     return ncclSuccess;
 }
@@ -125,7 +192,19 @@ ncclResult_t ncclAllGather(const void* sendbuff, void* recvbuff, size_t sendcoun
                            hipStream_t stream) {
     Double* d = reinterpret_cast<Double*>(comm);
     const size_t bytes = sendcount * type_size(datatype);
-    if (!d || !sendbuff || !recvbuff || bytes == 0 || bytes > kSlotBytes) return ncclInvalidArgument;
+    if (!d || !sendbuff || !recvbuff || bytes == 0) return ncclInvalidArgument;
+    if (d->local_group) {
+        // In-process ranks: inside a group the call is only noted; outside one, a lone rank can
+        // proceed and several would wait for each other for ever (as with the real library).
+        if (g_depth > 0) {
+            g_pending.push_back(Pending{d, sendbuff, recvbuff, bytes, stream});
+            return ncclSuccess;
+        }
+        if (d->world != 1) return ncclInvalidUsage;
+        std::vector<Pending> one{Pending{d, sendbuff, recvbuff, bytes, stream}};
+        return run_local(one);
+    }
+    if (bytes > kSlotBytes) return ncclInvalidArgument;
     if (hipStreamSynchronize(stream) != hipSuccess) return ncclUnhandledCudaError;
     if (hipMemcpy(d->slots + kSlotBytes * (size_t)d->rank, sendbuff, bytes, hipMemcpyDeviceToHost) != hipSuccess)
         return ncclUnhandledCudaError;

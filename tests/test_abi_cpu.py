@@ -122,7 +122,12 @@ def test_configure_from_config_reads_optional_keys():
         got = rag.configure_from_config({"local_index_dtype": "bf16", "local_retriever_devices": [3, 4],
                                          "local_top_k": 5, "local_window": 2})
         assert (got["store_dtype"], got["device"], got["top_k"], got["window"]) == ("bf16", 3, 5, 2)
-        assert rag.configure_from_config({"local_retriever_devices": 1})["device"] == 1
+        assert got["devices"] == [3, 4]          # the whole list: the index is row-sharded over it
+        assert rag.configure_from_config({"local_retriever_devices": 1})["devices"] == [1]
+        assert rag.configure_from_config({"local_retriever_devices": "2,0"})["devices"] == [2, 0]
+        assert rag.configure_from_config({"local_retriever_devices": []})["devices"] == [2, 0]   # empty: unchanged
+        with pytest.raises(ValueError):
+            rag.configure_from_config({"local_retriever_devices": [0, -1]})
         with pytest.raises(ValueError):
             rag.configure_from_config({"local_index_dtype": "int4"})
         with pytest.raises(ValueError):
@@ -141,12 +146,27 @@ def test_uploaded_list_fingerprint_sees_edits():
     assert b != a
     pages[0]["embedding"][0] = -1.0                       # vector edited in place
     assert rag._fingerprint(pages) != b
+    # every page is looked at, not a sample: page 137 of 200 is on no 64-page grid
+    c = rag._fingerprint(pages)
+    pages[137]["embedding"] = [float(137), 1.0, 2.0]      # replaced by an equal vector: a new object
+    d = rag._fingerprint(pages)
+    assert d != c
+    pages[138]["embedding"][-1] = 2.5                     # last value edited in place
+    assert rag._fingerprint(pages) != d
     pages.append({"index": 200, "text": "x", "embedding": [0.0, 0.0, 1.0]})
     assert rag._fingerprint(pages)[0] == 201
     m = np.zeros((50, 4), dtype=np.float32)
     fm = rag._fingerprint(m)
-    m[0, 0] = 3.0
+    m[33, 2] = 3.0                                        # any element of a matrix
     assert rag._fingerprint(m) != fm
+    import time
+    big = [{"index": i, "text": "", "embedding": [0.5] * 8} for i in range(4032)]
+    best = 1e9
+    for _ in range(5):
+        t0 = time.perf_counter()
+        rag._fingerprint(big)
+        best = min(best, time.perf_counter() - t0)
+    assert best < 0.05                                    # milliseconds at the reference's index size
 
 
 def test_one_hip_runtime_whatever_the_import_order():

@@ -185,3 +185,110 @@ def test_device_path_reports_nonfinite_queries(native):
     with pytest.raises(ValueError):
         shard.search_device(q, k=5, out=(other, torch.empty((2, 5), device="cuda")))
     shard.close()
+
+
+@pytest.mark.parametrize("store,n,d,batches", [("fp32", 1_000_000, 768, (1,)), ("bf16", 10_000_000, 1024, (1, 64)),
+                                               ("bf16", 12_500_000, 768, (1, 64))])
+def test_benchmark_shapes(native, store, n, d, batches):
+    """The shapes the benchmark numbers are quoted on, with the library's own
+    launch rules (no switches): 1M x 768 fp32 and 10M x 1024 bf16 with a single
+    query, the latter and one GPU's 12.5M x 768 bf16 share of the 100M-row corpus
+    also with a 64-query batch.  Rows are generated on the GPU; k rows per query
+    are planted for the first four queries and must come back, in order; the
+    oracle re-scores the original fp32 rows of (returned rows U 100k random rows);
+    a repeated search is identical."""
+    import torch
+    k = 10
+    corpus = torch.empty((n, d), device="cuda", dtype=torch.float32)
+    gen = torch.Generator(device="cuda").manual_seed(1000 + d)
+    step = 262_144
+    for lo in range(0, n, step):
+        hi = min(n, lo + step)
+        corpus[lo:hi] = torch.randn((hi - lo, d), generator=gen, device="cuda")
+    queries = torch.randn((max(max(batches), 4), d), generator=gen, device="cuda")
+    planted = {}
+    for q in range(4):
+        rows_q = [(q * 7919 + (2 * j + 1) * (n // (2 * k)) + 13) % n for j in range(k)]
+        for j, row in enumerate(rows_q):
+            cos = 0.95 - 0.45 * j / k
+            amp = (1.0 / (cos * cos) - 1.0) ** 0.5
+            corpus[row] = queries[q] / queries[q].norm() + amp * torch.randn(d, generator=gen, device="cuda") / d ** 0.5
+        planted[q] = rows_q
+    corpus[0] = queries[0] * 3.0                        # the shard's first row: cosine 1, ahead of the ten planted
+    planted[0] = [0] + planted[0]
+    for q, rows_q in planted.items():                   # expected order: by the rows' float64 cosine (the noise moves it a little)
+        cand = corpus[torch.tensor(rows_q, device="cuda")].double()
+        cos64 = (cand @ queries[q].double()) / (cand.norm(dim=1) * queries[q].double().norm())
+        order = torch.argsort(cos64, descending=True, stable=True).tolist()
+        assert float(cos64[order[k - 1]] - cos64[order[k]] if len(rows_q) > k else 1.0) > 2 * (1e-3 if store == "bf16" else 1e-6)
+        planted[q] = [rows_q[i] for i in order[:k]]
+    shard = native.DeviceShard.alloc(n, d, store_dtype=store)
+    for lo in range(0, n, 1 << 20):
+        shard.load_device(lo, corpus[lo:lo + (1 << 20)])
+    tol = 1e-3 if store == "bf16" else 1e-6
+    for b in batches:
+        q = queries[:b].contiguous()
+        gi, gs = (t.clone() for t in shard.search_device(q, k=k))
+        torch.cuda.synchronize()
+        assert not shard.nonfinite()
+        gi2, gs2 = shard.search_device(q, k=k)
+        torch.cuda.synchronize()
+        assert torch.equal(gi, gi2) and torch.equal(gs, gs2)
+        for qi in range(min(b, 4)):
+            assert gi[qi].tolist() == planted[qi], (b, qi)   # planted cosines are some 0.045 apart, far above the tolerance
+        pick = np.arange(0, b, max(1, b // 16))
+        nt = _check_against_subsample(torch, corpus, q[pick].cpu().numpy(), gi[pick].cpu().numpy(), gs[pick].cpu().numpy(),
+                                      k, tol, 100_000, 3)
+        hi_i, hi_s = shard.search(q[:1].cpu().numpy(), k=k)                    # the host entry on the same shard
+        if b == 1:
+            assert (hi_i == gi.cpu().numpy()).all() and (hi_s == gs.cpu().numpy()).all()
+        print(f"bench shape {store} {n}x{d} B={b}: {nt} near-tie differences on {len(pick)} queries")
+    shard.close()
+    del corpus
+
+
+def _bench_line(extra_args, env_extra):
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **env_extra)
+    for name in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(name, None)          # bench.py starts its own ranks from a bare environment
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + extra_args, env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, run.stdout                   # exactly ONE JSON line on stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("depth", [0, 2])
+def test_bench_multi_rank_command_rehearsed_on_one_gpu(depth):
+    """The command the driver issues for N > 1 (`bench.py --gpus N`, here N = 2 and
+    a small corpus) end to end: rank start-up, the communicator id broadcast,
+    agreement of the ranks on the exchange, the row shards, the fused and the
+    pipelined step, the max over ranks, ONE JSON line.  Both ranks share this
+    box's GPU, so the collective underneath the library's communicator is the
+    tests' stand-in (RCCL refuses two ranks on one device): a rehearsal of
+    bench.py's and the library's code, not a measurement."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    double = os.path.join(root, "tests", "rccl_double", "librccl_double.so")
+    assert os.path.exists(double)
+    res = _bench_line(["--gpus", "2", "--rehearse-on-one-gpu", "--rows", "400000", "--steps", "3", "--warmup", "2",
+                       "--pipeline-depth", str(depth)], {"MTR_RCCL_LIBRARY": double})
+    assert res["n_gpus"] == 2 and res["steps"] == 3 and res["needles_found"] is True
+    assert res["config"]["rows"] == 400000 and res["config"]["rows_per_gpu"] == 200000
+    assert "library's communicator" in res["config"]["exchange"] and res["config"]["exchange_pipeline_depth"] == depth
+    assert "400000x1024" in res["config"]["workload"] and res["value"] > 0
+    assert "cpu_baseline" not in res                      # rank 0 times the CPU only in single-GPU runs
+
+
+def test_bench_names_the_shape_it_ran():
+    """config.workload follows --rows / --batch / --k overrides."""
+    res = _bench_line(["--workload", "c2", "--rows", "300000", "--batch", "3", "--k", "5", "--steps", "3", "--warmup", "1",
+                       "--no-cpu-baseline"], {})
+    assert res["config"]["workload"].startswith("synthetic 300000x768 fp32 corpus, 3 queries/batch, exact top-5")
+    assert res["roofline"]["bound"] == "hbm" and res["needles_found"] is True

@@ -923,9 +923,41 @@ def _double_rank_worker(rank, world, port, ret, n):
             for x, (gi, gs) in zip(batches, got):
                 wi, ws = orc.search(x, corpus, 9, metric="ip")
                 ok = ok and bool((gi == wi).all()) and bool((gs == ws.astype(np.float32)).all())
+        # One rank's own search fails (cosine on rows stored without normalisation is refused on
+        # that rank only): it must still enter the all-gather, with padding, so that the others
+        # finish -- with the failing rank's rows missing -- and the communicator stays usable.
+        normed = None
+        if hi > lo and rank != 1:
+            normed = _native.DeviceShard.from_host(corpus[lo:hi], store_dtype="fp32", normalize=True, row_offset=lo)
+        failing = ShardedIndex(shard if rank == 1 else normed, comm=comm)
+        queries = rng.standard_normal((5, d)).astype(np.float32)
+        q = torch.from_numpy(queries).cuda()
+        lo1, hi1 = shard_bounds(n, world, 1)
+        try:
+            gi, gs = failing.search_device(q, k=6, metric="cosine")
+            torch.cuda.synchronize()
+            ok = ok and rank != 1
+            s64 = orc.scores(queries, corpus)
+            s64[:, lo1:hi1] = -np.inf                                      # the failing rank's rows are missing
+            have = n - (hi1 - lo1)
+            gi, gs = gi.cpu().numpy(), gs.cpu().numpy()
+            ok = ok and not ((gi >= lo1) & (gi < hi1)).any() and bool((gi[:, have:] == -1).all())
+            if have >= 6:
+                from parity import check_topk
+                check_topk(gi, gs, s64, 6, 1e-6)
+        except ValueError as exc:
+            ok = ok and rank == 1 and "normalize" in str(exc)
+        # ... and the next search is a matched collective again
+        queries = rng.integers(-3, 4, size=(2, d)).astype(np.float32)
+        gi, gs = index.search_device(torch.from_numpy(queries).cuda(), k=5, metric="ip")
+        torch.cuda.synchronize()
+        wi, ws = orc.search(queries, corpus, 5, metric="ip")
+        ok = ok and bool((gi.cpu().numpy() == wi).all()) and bool((gs.cpu().numpy() == ws.astype(np.float32)).all())
         ret[rank] = bool(ok)
         if shard is not None:
             shard.close()
+        if normed is not None:
+            normed.close()
         comm.close()
     finally:
         dist.destroy_process_group()
@@ -935,7 +967,8 @@ def _double_rank_worker(rank, world, port, ret, n):
 def test_library_communicator_with_several_ranks_over_a_stand_in(world, n):
     """csrc/comm_rccl.hip with MORE THAN ONE RANK: block layout, buffer rotation, the
     merge over every rank's gathered block, ranks without rows (2 rows over 3 ranks),
-    the fused call and the pipelined form.  RCCL itself refuses two ranks on one
+    the fused call and the pipelined form, and a search that fails on one rank only
+    (that rank still takes part in the all-gather; nobody is left waiting).  RCCL itself refuses two ranks on one
     GPU, so the collective underneath is the tests' shared-memory stand-in
     (tests/rccl_double, chosen with MTR_RCCL_LIBRARY): this checks the library's
     code around the all-gather, not RCCL.  Every rank must end with the unsharded

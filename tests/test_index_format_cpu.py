@@ -87,6 +87,27 @@ def test_bf16_sidecar_round_trip(tmp_path):
     assert index_format.read_header(mtr)["as_stored"] is False and index_format.open_sidecar(path)[0].dtype == np.float32
 
 
+@pytest.mark.parametrize("normalized", [True, False])
+def test_save_sidecar_marks_only_normalised_rows_as_stored(tmp_path, normalized):
+    """Rows of a shard built without normalisation must not skip it on the way back in."""
+    from medical_rag_amd import local_rag
+
+    rows = np.arange(12, dtype=np.float32).reshape(3, 4) + 1.0
+
+    class StubShard:
+        def info(self):
+            return {"store_dtype": "fp32", "normalized": normalized, "n": 3, "d": 4, "device": 0, "row_offset": 0}
+
+        def read_rows(self):
+            return rows
+
+    index = local_rag.PageIndex([{"index": i, "text": str(i)} for i in range(3)], StubShard())
+    path = str(tmp_path / "embedded_pages_hf_z.json")
+    mtr, _ = index.save_sidecar(path, bind_to_source=False)
+    assert fmt.read_header(mtr)["as_stored"] is normalized
+    np.testing.assert_array_equal(np.asarray(fmt.open_sidecar(path)[0]), rows)
+
+
 # ---------------------------------------------------------------------------
 # The library's reader of the reference's JSON index (host code, no GPU).
 # ---------------------------------------------------------------------------

@@ -139,5 +139,41 @@ def test_noalloc_search_can_be_captured_in_a_graph(native):
             want_i, want_s = shard.search_device(q, k=k)
             torch.cuda.synchronize()
             assert torch.equal(out[0], want_i) and torch.equal(out[1], want_s)
+            assert not shard.nonfinite()
+        # A replay with NaN in the queries reports it, the clean replay after it does not, and a
+        # search through another entry point in between (which takes a new epoch of the handle's
+        # ordinary report word) changes neither: no value frozen into the graph is compared.
+        clean = torch.randn((b, d), generator=gen, device="cuda")
+        q.copy_(clean)
+        q[b - 1, 17] = float("nan")
+        graph.replay()
+        torch.cuda.synchronize()
+        shard.search_device(clean, k=k)
+        torch.cuda.synchronize()
+        assert not shard.nonfinite()                      # the last search on the handle: the clean one
+        graph.replay()
+        torch.cuda.synchronize()
+        shard.search_device_noalloc(clean, out, k=k)      # the last call through the allocation-free entry: clean
+        torch.cuda.synchronize()
+        assert not shard.nonfinite()
+        q[0, 0] = float("inf")
+        with torch.cuda.stream(side):
+            shard.search_device_noalloc(q, out, k=k)      # marks the entry point as the handle's last device call
+        torch.cuda.synchronize()
+        assert shard.nonfinite()
+        q.copy_(clean)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert not shard.nonfinite()                      # the replay cleared the word and found nothing
+        q[0, 3] = float("nan")
+        graph.replay()
+        torch.cuda.synchronize()
+        assert shard.nonfinite()                          # ... and this one raised it again
+        q.copy_(clean)
+        graph.replay()
+        torch.cuda.synchronize()
+        want_i, want_s = shard.search_device(clean, k=k)
+        torch.cuda.synchronize()
+        assert torch.equal(out[0], want_i) and torch.equal(out[1], want_s)
         del graph
     shard.close()
