@@ -239,6 +239,11 @@ struct StaticScratch {
     bool allows_wide() const { return false; }   // its key lists run to gigabytes
 };
 
+// The words of the handle's flag block through which the waves of the streaming
+// single-query scan claim rows (words 32..63 of 64; zero between launches:
+// the last wave of a launch clears them).
+unsigned int* scan_sync(mtr_index* ix) { return reinterpret_cast<unsigned int*>(ix->flag) + 32; }
+
 // Makes `stream` wait for whatever was last enqueued on the handle from another
 // stream (the scratch buffers, the non-finite flag and the staging buffers are
 // shared), and marks the end of the newly enqueued work.
@@ -488,7 +493,7 @@ int enqueue_search(mtr_index* ix, S& sc, const void* dev_queries, int q_dtype, i
         }
         HIP_TRY(mtr::launch_scan_topk(ix->rows, ix->dtype, ix->n, ix->ld, ix->d, q_f32,
                                       raw ? reinterpret_cast<const float*>(qsrc) : nullptr, nb,
-                                      metric == MTR_COSINE ? 1 : 0, nf, k, plan, cand_s, cand_i, stream));
+                                      metric == MTR_COSINE ? 1 : 0, nf, k, plan, cand_s, cand_i, scan_sync(ix), stream));
         if (profiling) HIP_TRY(hipEventRecord(e1, stream));
         // the scan's per-workgroup lists are sorted best first
         HIP_TRY(mtr::launch_merge_sorted_lists(cand_s, cand_i, plan.grid, (long long)k, (long long)plan.grid * k, k, nb, k,
@@ -883,7 +888,7 @@ int mtr_index_read_ceiling(mtr_index_t* ix, int32_t reps, float* avg_ms) {
     for (int r = 0; r < reps + 1 && err == hipSuccess; ++r) {   // the first launch warms up
         float ms = 0.f;
         if ((err = hipEventRecord(e0, ix->stream)) != hipSuccess) break;
-        if ((err = mtr::launch_scan_read_only(ix->rows, ix->dtype, ix->n, ix->ld, ix->d, plan, sink, ix->stream)) != hipSuccess) break;
+        if ((err = mtr::launch_scan_read_only(ix->rows, ix->dtype, ix->n, ix->ld, ix->d, plan, sink, scan_sync(ix), ix->stream)) != hipSuccess) break;
         if ((err = hipEventRecord(e1, ix->stream)) != hipSuccess) break;
         if ((err = hipEventSynchronize(e1)) != hipSuccess) break;
         if ((err = hipEventElapsedTime(&ms, e0, e1)) != hipSuccess) break;
@@ -941,7 +946,7 @@ const TuningField kTuningFields[] = {
     {"mfma_sample_stride", &mtr::Tuning::mfma_sample_stride}, {"mfma_stream_rows", &mtr::Tuning::mfma_stream_rows},
     {"mfma_stages", &mtr::Tuning::mfma_stages},           {"mfma_tile_rows", &mtr::Tuning::mfma_tile_rows},
     {"wide_min_batch", &mtr::Tuning::wide_min_batch},     {"wide_qgroup", &mtr::Tuning::wide_qgroup},
-        {"scan_wg_per_cu", &mtr::Tuning::scan_wg_per_cu},
+    {"scan_wg_per_cu", &mtr::Tuning::scan_wg_per_cu},     {"scan_form", &mtr::Tuning::scan_form},
     {"scan_nontemporal", &mtr::Tuning::scan_nontemporal}, {"scan_max_qb", &mtr::Tuning::scan_max_qb}, {"pool_sliced", &mtr::Tuning::pool_sliced},
 #ifdef MTR_TIMING_SWITCHES
     {"timing_mfma", &mtr::Tuning::timing_mfma},           {"timing_wide", &mtr::Tuning::timing_wide},

@@ -60,6 +60,7 @@ struct Tuning {
     int scan_wg_per_cu = 0;       // scan workgroups per CU (0: one for a single query, occupancy otherwise)
     int scan_max_qb = 0;          // most queries per scan pass 1 / 2 / 4 / 8 (0: four)
     int scan_nontemporal = -1;    // -1: streaming row loads on shards beyond the caches; 0 / 1
+    int scan_form = 0;            // single-query scan: 0 by shard size; 1 classic form; 2 streaming form wherever the shape allows
     int pool_sliced = -1;         // pooling kernel form: -1 by shape (two kernels from 256 tokens); 0 one kernel; 1 two kernels
     int timing_mfma = 0;          // MTR_TIMING_SWITCHES builds only: drop candidates / skip loads or MFMAs (wrong results)
     int timing_wide = 0;          // MTR_TIMING_SWITCHES builds only
@@ -103,6 +104,8 @@ struct ScanPlan {
     int grid;        // workgroups
     size_t lds;      // dynamic LDS bytes
     int nontemporal; // stream rows past the caches
+    int stream_sweeps; // 0: classic form; else the streaming single-query form (four waves, sixteen-row groups,
+                     // two register sets, claimed tail) with this many sweeps per unit; grid and lds are then its own
 };
 
 // Chooses the pass width and launch shape for the row scan.
@@ -111,12 +114,14 @@ int plan_scan(int dtype, int64_t n, int d, int ld, int b, int k, int num_cus, Sc
 // Row scan + fused per-workgroup top-k.  q: plan.qb padded fp32 queries
 // ([qb][qstride]); outputs [qb][grid][k] candidate (score, local row) lists,
 // each sorted, padded with (-inf, -1).
+// sync: 32 device words, zero between launches, that the streaming form's waves claim rows
+// through (a shard's launches must not overlap on them); unused by the classic form.
 // Instead of prepared queries (q), the first nb raw fp32 queries ([nb][d],
 // q_raw != NULL) can be given: every workgroup then normalises (if asked) and
 // pads them itself and reports NaN/inf through nonfinite_flag.
 hipError_t launch_scan_topk(const void* rows, int dtype, int64_t n, int ld, int d, const float* q,
                             const float* q_raw, int nb, int normalize, NonfiniteFlag nonfinite_flag, int k,
-                            const ScanPlan& plan, float* cand_s, int* cand_i, hipStream_t stream);
+                            const ScanPlan& plan, float* cand_s, int* cand_i, unsigned int* sync, hipStream_t stream);
 
 // Candidate merge: for each of b queries, the best k_out of n_lists * k_in
 // candidates.  Candidate (list l, query q, slot j) sits at
@@ -137,7 +142,7 @@ hipError_t launch_pool_normalize(const void* hidden, int dtype, const long long*
 // The single-query scan's loads without its arithmetic (plan from plan_scan with b = 1): a
 // live measurement of what the memory system delivers to the scan's access pattern.
 hipError_t launch_scan_read_only(const void* rows, int dtype, int64_t n, int ld, int d, const ScanPlan& plan,
-                                 unsigned int* sink, hipStream_t stream);
+                                 unsigned int* sink, unsigned int* sync, hipStream_t stream);
 
 struct MfmaPlan {
     int cap;                  // candidate slots per (workgroup, query): 256 or 512

@@ -23,6 +23,13 @@
 //     waves of a workgroup fold their lists pairwise
 //     at the end and the workgroup writes one sorted candidate list per query.
 //
+//
+// Single queries on shards beyond the caches take the streaming form
+// (scan_stream_kernel): four waves per workgroup, groups of sixteen rows, two
+// register sets so that the next batch of loads is requested before the
+// current one is consumed, and a dynamic split of the last rows between the
+// waves (see there).
+//
 // Algorithmic bytes per launch: n * ld * sizeof(T) (each stored row byte is
 // read once); the query and candidate traffic is negligible beside it.
 #include <stdlib.h>
@@ -350,6 +357,376 @@ __global__ __launch_bounds__(waves_per_group(1) * 64) void scan_read_only_kernel
     if (x == 0x9e3779b9u) sink[0] = x;   // never on real data in practice; keeps the loads alive
 }
 
+// ---- streaming form: one query, shards beyond the caches ----------------------
+//
+// What the memory system delivers to a CU differs between CUs by several per
+// cent (with the rows split evenly, the first workgroups of a 2.85 ms scan
+// finish at 2.6 ms), so an even split ends when the slowest CU does.  Here a
+// wave takes a fixed share of the groups first (most of them: wave w of W takes
+// groups w, w + W, ...), and the rest is handed out through a device-wide
+// counter in chunks of two groups and finally of one.  The claims are few (the
+// counter takes about one claim per 5 ns) and are made by a fifth wave of the
+// workgroup, which does nothing else: an atomic with return sits in its wave's
+// queue of loads, which return in order, so in a scanning wave a slow claim
+// would hold back the rows requested behind it.  The claimer keeps one claimed
+// chunk per scanning wave in an LDS box; a wave that empties its box finds it
+// refilled by the time it has scanned the chunk.
+//
+// The scanning loop takes two units (a unit = SWEEPS sweeps of a group's four
+// row quads) per trip, one per register set, and requests a unit before it
+// consumes the previous one; every wait on the loads is counted.  That needs:
+//   - no branch around a load or its consumption (the compiler cannot count
+//     loads in flight across a join and waits for all of them): a request
+//     past the wave's last unit re-reads that unit, and its sums are dropped;
+//   - nothing in flight at the loop's entry that the loop does not know of (the
+//     query set-up's loads are waited for explicitly before it);
+//   - the wave index in a scalar register (readfirstlane), so that unit
+//     counters and loop tests are scalar;
+//   - __launch_bounds__ of the real workgroup size, or the second register set
+//     is spilled (the compiler assumes 1024 threads and 128 registers).
+constexpr int kStreamWaves = 4;                     // scanning waves; one more wave claims chunks for them
+constexpr int kStreamThreads = (kStreamWaves + 1) * 64;
+constexpr unsigned int kBoxEmpty = 0xffffffffu;
+constexpr int kStreamQuads = 4;                     // 16 rows per group
+constexpr int kStreamGroupRows = 4 * kStreamQuads;
+
+struct StreamSplit {
+    long long ngroups;          // groups of 16 rows
+    long long static_groups;    // groups every wave takes by its index (wave w: w, w + W, ...)
+    long long dyn_first;        // first group of the claimed part = static_groups * W
+    long long pairs;            // chunks of two groups at the start of the claimed part; single groups follow
+    unsigned int* sync;         // [0] claim counter, [16] workgroups whose claimer has finished; both zero between launches
+};
+
+__device__ __forceinline__ bool stream_chunk(const StreamSplit& sp, long long slot, long long& g0, long long& g1) {
+    if (slot < sp.pairs) { g0 = sp.dyn_first + 2 * slot; g1 = g0 + 2; return true; }
+    g0 = sp.dyn_first + 2 * sp.pairs + (slot - sp.pairs);
+    g1 = g0 + 1;
+    return g0 < sp.ngroups;
+}
+
+struct StreamUnit {
+    long long g;
+    int s0;
+};
+
+template <bool NT, int SWEEPS>
+__device__ __forceinline__ void stream_request(const ScanArgs& a, StreamUnit u, int col, int lrow,
+                                               u32x4 (&raw)[SWEEPS][kStreamQuads]) {
+    const char* rp[kStreamQuads];
+#pragma unroll
+    for (int qd = 0; qd < kStreamQuads; ++qd) {
+        long long row = u.g * kStreamGroupRows + qd * 4 + lrow;
+        row = row < a.n ? row : a.n - 1;
+        rp[qd] = a.rows + row * a.row_bytes;
+    }
+#pragma unroll
+    for (int s = 0; s < SWEEPS; ++s) {
+        const int chunk = (u.s0 + s) * kLanesPerRow + col;
+        const int chunk_c = chunk < a.nchunks ? chunk : 0;   // past the row's data: chunk 0, times a zero query value
+#pragma unroll
+        for (int qd = 0; qd < kStreamQuads; ++qd)
+            raw[s][qd] = load_chunk<NT>(reinterpret_cast<const u32x4*>(rp[qd] + (size_t)chunk_c * 16));
+    }
+}
+
+template <typename T, int SWEEPS, bool ARITH>
+__device__ __forceinline__ void stream_consume(const float* q_lds, StreamUnit u, int col,
+                                               const u32x4 (&raw)[SWEEPS][kStreamQuads], float (&acc)[kStreamQuads],
+                                               unsigned int& x) {
+    constexpr int EPC = Chunk<T>::EPC;
+#pragma unroll
+    for (int s = 0; s < SWEEPS; ++s) {
+        if constexpr (ARITH) {
+            const int chunk = (u.s0 + s) * kLanesPerRow + col;
+            float qv[EPC];
+            const f32x4* qp = reinterpret_cast<const f32x4*>(q_lds + (size_t)chunk * EPC);
+#pragma unroll
+            for (int e4 = 0; e4 < EPC / 4; ++e4) {
+                const f32x4 t = qp[e4];
+                qv[4 * e4 + 0] = t[0]; qv[4 * e4 + 1] = t[1];
+                qv[4 * e4 + 2] = t[2]; qv[4 * e4 + 3] = t[3];
+            }
+#pragma unroll
+            for (int qd = 0; qd < kStreamQuads; ++qd) {
+                float f[EPC];
+                Chunk<T>::unpack(raw[s][qd], f);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) acc[qd] = __builtin_fmaf(f[e], qv[e], acc[qd]);
+            }
+        } else {
+#pragma unroll
+            for (int qd = 0; qd < kStreamQuads; ++qd) x ^= raw[s][qd][0] ^ raw[s][qd][1] ^ raw[s][qd][2] ^ raw[s][qd][3];
+        }
+    }
+}
+
+// One raw fp32 query -> normalised, zero-padded fp32 in LDS, by one wave
+// (float64 norm; a norm below 10 * DBL_EPSILON counts as 1, as for the rows).
+__device__ __forceinline__ void stage_raw_query(const ScanArgs& a, const float* src, float* dst, int lane, bool report) {
+    double ss = 0.0;
+    bool bad = false;
+    constexpr int kBatch = 16;
+    for (int e0 = lane; e0 < a.d; e0 += 64 * kBatch) {
+        float v[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const int e = e0 + 64 * u;
+            v[u] = src[e < a.d ? e : lane];
+        }
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            if (e0 + 64 * u < a.d) {
+                const double x = (double)v[u];
+                bad |= !(fabs(x) <= 1.7976931348623157e308);
+                ss += x * x;
+            }
+        }
+    }
+    if (__ballot(bad) != 0ull && lane == 0 && report) atomicMax(a.nonfinite_flag.word, a.nonfinite_flag.value);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        int lo = __double2loint(ss), hi = __double2hiint(ss);
+        lo = __shfl_xor(lo, m, 64);
+        hi = __shfl_xor(hi, m, 64);
+        ss += __hiloint2double(hi, lo);
+    }
+    double norm = 1.0;
+    if (a.normalize) {
+        norm = sqrt(ss);
+        if (!(norm >= 10.0 * 2.220446049250313e-16)) norm = 1.0;
+    }
+    for (int e0 = lane; e0 < a.qstride; e0 += 64 * kBatch) {
+        float v[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const int e = e0 + 64 * u;
+            v[u] = src[e < a.d ? e : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const int e = e0 + 64 * u;
+            if (e < a.qstride) dst[e] = e < a.d ? (float)((double)v[u] / norm) : 0.f;
+        }
+    }
+}
+
+// ARITH false: the same loads, claims and waits without the arithmetic and the
+// top-k (the ceiling measurement of this form).
+template <typename T, bool NT, int SWEEPS, bool ARITH>
+__global__ __launch_bounds__(kStreamThreads) void scan_stream_kernel(ScanArgs a, StreamSplit sp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* q_lds = reinterpret_cast<float*>(smem);
+    float* list_s = q_lds + a.qstride;
+    int* list_i = reinterpret_cast<int*>(list_s + kStreamWaves * a.k);
+    int* cnt_lds = list_i + kStreamWaves * a.k;
+    unsigned int* box = reinterpret_cast<unsigned int*>(cnt_lds + kStreamWaves);   // one claimed slot per scanning wave
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int kFoldBarriers = ARITH ? 4 : 0;   // two per halving round of the final fold
+
+    if (wave == kStreamWaves) {
+        // ---- the claimer: lane l keeps the box of scanning wave l filled ----
+        if (lane < kStreamWaves) box[lane] = kBoxEmpty;
+        __syncthreads();
+        bool finished = lane >= kStreamWaves;   // ... until it has handed it a slot past the end
+        while (__ballot(!finished) != 0ull) {
+            if (!finished && __hip_atomic_load(&box[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == kBoxEmpty) {
+                const unsigned int slot = __hip_atomic_fetch_add(sp.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&box[lane], slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                long long c0, c1;
+                finished = !stream_chunk(sp, (long long)slot, c0, c1);
+            }
+            __builtin_amdgcn_s_sleep(16);
+        }
+        // This workgroup claims nothing more; the last claimer of the launch to get
+        // here leaves both counters at zero for the next launch.
+        if (lane == 0) {
+            const unsigned int before = __hip_atomic_fetch_add(sp.sync + 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (before + 1u == gridDim.x) {
+                __hip_atomic_store(sp.sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(sp.sync + 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < kFoldBarriers; ++i) __syncthreads();
+        return;
+    }
+
+    const int col = lane & (kLanesPerRow - 1);
+    const int lrow = lane >> 4;
+    const long long W = (long long)gridDim.x * kStreamWaves;
+    const long long wid = (long long)blockIdx.x * kStreamWaves + wave;
+
+    // Iterator over the wave's units, kept one unit ahead of the consumption.
+    long long g = wid, g_end = wid + 1, j_static = 0;
+    int s0 = 0;
+    bool valid = sp.static_groups > 0;   // the launcher only picks this form for shards with many groups per wave
+    auto advance = [&]() {
+        if (!valid) return;
+        s0 += SWEEPS;
+        if (s0 < a.nit) return;
+        s0 = 0;
+        g += 1;
+        if (g < g_end) return;
+        if (++j_static < sp.static_groups) { g = wid + j_static * W; g_end = g + 1; return; }
+        // the chunk the claimer has put into this wave's box (refilled while the chunk is scanned)
+        unsigned int slot;
+        while ((slot = (unsigned int)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(
+                    &box[wave], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) == kBoxEmpty)
+            __builtin_amdgcn_s_sleep(1);
+        long long c0, c1;
+        if (stream_chunk(sp, (long long)slot, c0, c1)) {
+            g = c0; g_end = c1;
+            if (lane == 0) __hip_atomic_store(&box[wave], kBoxEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            valid = false;   // slots are handed out in order: every later one is past the end too
+        }
+    };
+
+    u32x4 ra[SWEEPS][kStreamQuads], rb[SWEEPS][kStreamQuads];
+    StreamUnit cur{g, s0};
+    bool cur_ok = valid;
+    // The rows do not depend on the query: the first unit's loads go out before
+    // the query set-up (two dependent rounds of global loads and a barrier).
+    if (cur_ok) stream_request<NT, SWEEPS>(a, cur, col, lrow, ra);
+
+    if constexpr (ARITH) {
+        if (a.q_raw) {
+            if (wave == 0) stage_raw_query(a, a.q_raw, q_lds, lane, blockIdx.x == 0);
+        } else {
+            const int n4 = a.qstride / 4;
+            const f32x4* src = reinterpret_cast<const f32x4*>(a.q);
+            f32x4* dst = reinterpret_cast<f32x4*>(q_lds);
+            for (int i = tid; i < n4; i += kStreamWaves * 64) dst[i] = src[i];
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): nothing the loop does not know of is in flight when it starts
+
+    WaveTopK<int> tk;
+    tk.init(list_s + wave * a.k, list_i + wave * a.k, a.k);
+    float acc[kStreamQuads];
+#pragma unroll
+    for (int qd = 0; qd < kStreamQuads; ++qd) acc[qd] = 0.f;
+    unsigned int x = 0;
+
+    auto finish_group = [&](long long grp) {
+        if constexpr (ARITH) {
+            float total = 0.f;
+#pragma unroll
+            for (int qd = 0; qd < kStreamQuads; ++qd) {
+                const float t = row16_sum(acc[qd]);
+                if (col == qd) total = t;
+                acc[qd] = 0.f;
+            }
+            const long long row = grp * kStreamGroupRows + col * 4 + lrow;
+            tk.push(total, (int)row, col < kStreamQuads && row < a.n);
+        }
+    };
+
+    while (cur_ok) {
+        advance();
+        const bool nx_ok = valid;
+        const StreamUnit nx = nx_ok ? StreamUnit{g, s0} : cur;
+        stream_request<NT, SWEEPS>(a, nx, col, lrow, rb);
+        __builtin_amdgcn_sched_barrier(0);   // or the scheduler moves the consumption in front of the requests
+        stream_consume<T, SWEEPS, ARITH>(q_lds, cur, col, ra, acc, x);
+        if (cur.s0 + SWEEPS >= a.nit) finish_group(cur.g);
+        advance();
+        const bool c2_ok = valid;
+        const StreamUnit c2 = c2_ok ? StreamUnit{g, s0} : cur;
+        stream_request<NT, SWEEPS>(a, c2, col, lrow, ra);
+        __builtin_amdgcn_sched_barrier(0);
+        // consumed even without a next unit (a copy of the last one; nobody reads its sums)
+        stream_consume<T, SWEEPS, ARITH>(q_lds, nx, col, rb, acc, x);
+        if (nx_ok && nx.s0 + SWEEPS >= a.nit) finish_group(nx.g);
+        cur = c2;
+        cur_ok = c2_ok;
+    }
+
+    if constexpr (!ARITH) {
+        if (x == 0x9e3779b9u) a.cand_i[0] = (int)x;   // never on real data in practice; keeps the loads alive
+    } else {
+#pragma unroll
+        for (int half = kStreamWaves / 2; half >= 1; half >>= 1) {
+            if (lane == 0 && wave < 2 * half) cnt_lds[wave] = tk.cnt;
+            __syncthreads();
+            if (wave < half) {
+                const int w = wave + half;
+                const int c = cnt_lds[w];
+                const float* ws = list_s + w * a.k;
+                const int* wi = list_i + w * a.k;
+                for (int j0 = 0; j0 < c; j0 += 64) {
+                    const int j = j0 + lane;
+                    const bool ok = j < c;
+                    const float s = ok ? ws[j] : 0.f;
+                    const int i = ok ? wi[j] : 0;
+                    tk.push(s, i, ok);
+                }
+            }
+            __syncthreads();
+        }
+        if (wave == 0) {
+            float* os = a.cand_s + (size_t)blockIdx.x * a.k;
+            int* oi = a.cand_i + (size_t)blockIdx.x * a.k;
+            for (int j = lane; j < a.k; j += 64) {
+                const bool ok = j < tk.cnt;
+                os[j] = ok ? tk.ls[j] : -__builtin_huge_valf();
+                oi[j] = ok ? tk.li[j] : -1;
+            }
+        }
+    }
+}
+
+size_t stream_lds_bytes(int qstride, int k) {
+    return (size_t)qstride * 4 + (size_t)kStreamWaves * k * 8 + (size_t)kStreamWaves * 4 + (size_t)kStreamWaves * 4;
+}
+
+// Sweeps per unit: the largest of 4, 3, 2 that divides the sweeps of a row (a
+// unit never crosses a group); 0 when none does.
+int stream_sweeps(int nit) { return nit % 4 == 0 ? 4 : nit % 3 == 0 ? 3 : nit % 2 == 0 ? 2 : 0; }
+
+StreamSplit stream_split(int64_t n, int grid, unsigned int* sync) {
+    StreamSplit sp;
+    const long long W = (long long)grid * kStreamWaves;
+    sp.ngroups = (n + kStreamGroupRows - 1) / kStreamGroupRows;
+    // 96 % of the groups by index; of the rest, pairs up to 99.5 %, then single groups: on
+    // 10M x 2048 B about 16 K claims, which the counter takes without queueing
+    sp.static_groups = (long long)(0.96 * (double)sp.ngroups) / W;
+    sp.dyn_first = sp.static_groups * W;
+    const long long pair_end = (long long)(0.995 * (double)sp.ngroups);
+    sp.pairs = pair_end > sp.dyn_first ? (pair_end - sp.dyn_first) / 2 : 0;
+    sp.sync = sync;
+    return sp;
+}
+
+template <typename T, bool NT, bool ARITH>
+hipError_t launch_stream(const ScanArgs& a, const ScanPlan& plan, const StreamSplit& sp, hipStream_t stream) {
+    const size_t lds = ARITH ? plan.lds : stream_lds_bytes(plan.qstride, 1);
+#define MTR_STREAM_CASE(S)                                                                                             \
+    case S: {                                                                                                          \
+        if (lds > 48 * 1024) {                                                                                         \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_stream_kernel<T, NT, S, ARITH>),    \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                  \
+            if (e != hipSuccess) return e;                                                                             \
+        }                                                                                                              \
+        hipLaunchKernelGGL((scan_stream_kernel<T, NT, S, ARITH>), dim3(plan.grid), dim3(kStreamThreads), lds,         \
+                           stream, a, sp);                                                                             \
+        break;                                                                                                         \
+    }
+    switch (plan.stream_sweeps) {
+        MTR_STREAM_CASE(2)
+        MTR_STREAM_CASE(3)
+        MTR_STREAM_CASE(4)
+        default: return hipErrorInvalidValue;
+    }
+#undef MTR_STREAM_CASE
+    return hipGetLastError();
+}
+
 size_t scan_lds_bytes(int qb, int qstride, int k) {
     const int kWaves = waves_per_group(qb);
     return (size_t)qb * qstride * 4 + (size_t)kWaves * qb * k * 8 + (size_t)kWaves * qb * 4;
@@ -434,13 +811,45 @@ int plan_scan(int dtype, int64_t n, int d, int ld, int b, int k, int num_cus, Sc
     if (tuning().scan_wg_per_cu > 0) cap = (long long)num_cus * tuning().scan_wg_per_cu;
     plan->grid = (int)(want < cap ? want : cap);
     if (plan->grid < 1) plan->grid = 1;
+    // One query per pass on a shard beyond the caches: the streaming form, one
+    // workgroup of four waves per CU, when a row's sweeps split into whole units
+    // and every wave has groups to take by index (tuning: scan_form 1 keeps
+    // the classic form, 2 takes the streaming form whenever the shape allows it).
+    plan->stream_sweeps = 0;
+    const int sweeps = stream_sweeps(plan->nit);
+    const int sgrid = num_cus * (tuning().scan_wg_per_cu > 0 ? tuning().scan_wg_per_cu : 1);
+    const long long sgroups = (n + kStreamGroupRows - 1) / kStreamGroupRows;
+    const bool can_stream = qb == 1 && sweeps != 0 && sgroups >= 2ll * sgrid * kStreamWaves &&
+                            stream_lds_bytes(plan->qstride, k) <= kLdsBudget;
+    const bool want_stream = tuning().scan_form == 2 || (tuning().scan_form != 1 && plan->nontemporal &&
+                                                         sgroups >= 16ll * sgrid * kStreamWaves);
+    if (can_stream && want_stream) {
+        plan->stream_sweeps = sweeps;
+        plan->grid = sgrid;
+        plan->lds = stream_lds_bytes(plan->qstride, k);
+    }
     return 0;
 }
 
 hipError_t launch_scan_read_only(const void* rows, int dtype, int64_t n, int ld, int d, const ScanPlan& plan,
-                                 unsigned int* sink, hipStream_t stream) {
+                                 unsigned int* sink, unsigned int* sync, hipStream_t stream) {
     const int esize = dtype == 0 ? 4 : 2;
     const int nchunks = (d * esize + 15) / 16;
+    if (plan.stream_sweeps) {
+        if (!sync) return hipErrorInvalidValue;
+        ScanArgs a = {};
+        a.rows = static_cast<const char*>(rows);
+        a.n = n;
+        a.row_bytes = (long long)ld * esize;
+        a.nchunks = nchunks;
+        a.nit = plan.nit;
+        a.qstride = plan.qstride;
+        a.k = 1;
+        a.cand_i = reinterpret_cast<int*>(sink);
+        const StreamSplit sp = stream_split(n, plan.grid, sync);
+        return plan.nontemporal ? launch_stream<bf16_t, true, false>(a, plan, sp, stream)
+                                : launch_stream<bf16_t, false, false>(a, plan, sp, stream);
+    }
     if (plan.nontemporal)
         hipLaunchKernelGGL(scan_read_only_kernel<true>, dim3(plan.grid), dim3(waves_per_group(1) * 64), 0, stream,
                            static_cast<const char*>(rows), (long long)n, (long long)ld * esize, nchunks, plan.nit, sink);
@@ -452,7 +861,7 @@ hipError_t launch_scan_read_only(const void* rows, int dtype, int64_t n, int ld,
 
 hipError_t launch_scan_topk(const void* rows, int dtype, int64_t n, int ld, int d, const float* q,
                             const float* q_raw, int nb, int normalize, NonfiniteFlag nonfinite_flag, int k,
-                            const ScanPlan& plan, float* cand_s, int* cand_i, hipStream_t stream) {
+                            const ScanPlan& plan, float* cand_s, int* cand_i, unsigned int* sync, hipStream_t stream) {
     const int esize = dtype == 0 ? 4 : 2;
     ScanArgs a;
     a.rows = static_cast<const char*>(rows);
@@ -470,6 +879,15 @@ hipError_t launch_scan_topk(const void* rows, int dtype, int64_t n, int ld, int 
     a.k = k;
     a.cand_s = cand_s;
     a.cand_i = cand_i;
+    if (plan.stream_sweeps) {
+        if (!sync || plan.qb != 1) return hipErrorInvalidValue;
+        const StreamSplit sp = stream_split(n, plan.grid, sync);
+        if (dtype == 0)
+            return plan.nontemporal ? launch_stream<float, true, true>(a, plan, sp, stream)
+                                    : launch_stream<float, false, true>(a, plan, sp, stream);
+        return plan.nontemporal ? launch_stream<bf16_t, true, true>(a, plan, sp, stream)
+                                : launch_stream<bf16_t, false, true>(a, plan, sp, stream);
+    }
     if (dtype == 0)
         return plan.nontemporal ? launch_qb<float, true>(a, plan, stream) : launch_qb<float, false>(a, plan, stream);
     return plan.nontemporal ? launch_qb<bf16_t, true>(a, plan, stream) : launch_qb<bf16_t, false>(a, plan, stream);
