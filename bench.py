@@ -191,6 +191,9 @@ def main():
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--k", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ceiling", action="store_true",
+                    help="skip the loads-only twin of the scan after the timed region (for counter passes: it is an "
+                         "instantiation of the same kernel)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="initialise the process group and run the all-gather + merge even with one rank")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -334,7 +337,8 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    ceiling_ms = shard.read_ceiling(20) if (rank == 0 and batch == 1) else None
+    last_kernel = shard.last_kernel()
+    ceiling_ms = shard.read_ceiling(20) if (rank == 0 and batch == 1 and not args.no_ceiling) else None
     n_launch, scan_ms = shard.scan_time()
     samples = sorted(shard.scan_samples())
     shard.profile(False)
@@ -382,6 +386,8 @@ def main():
         wide_min = int(os.environ.get("MTR_WIDE_MIN_BATCH", "129"))
         if on_mfma and store == "bf16" and batch >= wide_min and local_bytes >= 1.0e9:
             kernel = "score_filter_wide_kernel"
+        kernel = last_kernel or kernel           # what the library says it launched
+        on_mfma = kernel in ("score_topk_mfma_kernel", "score_filter_wide_kernel")
         flops = 2.0 * batch * (hi - lo) * dim
         peak_tf = MFMA_PEAK_TFLOPS[store]
         # the roofline that binds is the one whose minimum time is longer
@@ -400,8 +406,8 @@ def main():
             # the scan's loads alone (no arithmetic), measured in this run on this shard
             roof["ceiling_measured"] = {"GBps": local_bytes / (ceiling_ms * 1e-3) / 1e9, "kernel_ms": ceiling_ms,
                                         "frac_of_ceiling": ceiling_ms / scan_avg_ms,
-                                        "what": "scan_read_only_kernel: the single-query scan's access pattern, launch "
-                                                "shape and cache policy without its arithmetic, 20 launches"}
+                                        "what": "the single-query scan's loads without its arithmetic (same kernel form, "
+                                                "launch shape, cache policy and row hand-out), 20 launches"}
         if traffic is not None:
             roof["traffic_source"] = (f"{traffic_file}: separate rocprofv3 --pmc passes over this command, committed; "
                                       "not collected during this run")

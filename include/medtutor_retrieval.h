@@ -310,6 +310,14 @@ int mtr_index_scan_samples(mtr_index_t* index, float* out_ms, int32_t cap, int32
  * reference. */
 int mtr_index_read_ceiling(mtr_index_t* index, int32_t reps, float* avg_ms);
 
+/* The name of the scoring kernel the last search enqueued on the shard took
+ * ("scan_topk_kernel", "scan_stream_kernel", "score_topk_mfma_kernel" or
+ * "score_filter_wide_kernel"; "" before the first search), NUL-terminated
+ * into buf (cap bytes).  For benchmark reports and profiles, which otherwise
+ * would have to restate the library's launch rules.  No counterpart in the
+ * reference. */
+int mtr_index_last_kernel(const mtr_index_t* index, char* buf, int32_t cap);
+
 void mtr_index_destroy(mtr_index_t* index);
 
 /* Process-wide launch-shape switches, for parity tests (which force the
@@ -317,6 +325,8 @@ void mtr_index_destroy(mtr_index_t* index);
  * for normal use.  Names: mfma_min_batch, mfma_tnq, mfma_per_cu, mfma_cap,
  * mfma_sample_stride, mfma_stream_rows, mfma_stages, mfma_tile_rows,
  * wide_min_batch, wide_qgroup, scan_wg_per_cu, scan_nontemporal, scan_max_qb,
+ * scan_form, scan_static_permille, scan_chunk_groups, scan_mid_permille,
+ * scan_pair_permille, scan_late_refill,
  * pool_sliced.  Each starts from the environment variable MTR_<NAME> if set.  Unknown name: MTR_ERR_INVALID.
  * No counterpart in the reference. */
 int mtr_tuning_set(const char* name, int32_t value);

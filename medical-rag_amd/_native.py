@@ -66,6 +66,7 @@ SIGNATURES = {
     "mtr_tuning_set": (_i32, [C.c_char_p, _i32]),
     "mtr_tuning_get": (_i32, [C.c_char_p, C.POINTER(_i32)]),
     "mtr_index_read_ceiling": (_i32, [_vp, _i32, C.POINTER(C.c_float)]),
+    "mtr_index_last_kernel": (_i32, [_vp, C.c_char_p, _i32]),
     "mtr_json_index_scan": (_i32, [_vp, _i64, _pp]),
     "mtr_json_index_info": (_i32, [_vp, C.POINTER(_i64), C.POINTER(_i32), C.POINTER(_i64)]),
     "mtr_json_index_read": (_i32, [_vp, _vp, _i32, _vp, _i32]),
@@ -430,6 +431,12 @@ class DeviceShard:
         buf = (C.c_float * max(n.value, 1))()
         check(lib().mtr_index_scan_samples(self._h, buf, n.value, C.byref(n)))
         return [buf[i] for i in range(n.value)]
+
+    def last_kernel(self) -> str:
+        """Name of the scoring kernel the last search on this shard took."""
+        buf = C.create_string_buffer(64)
+        check(lib().mtr_index_last_kernel(self._h, buf, 64))
+        return buf.value.decode()
 
     def read_ceiling(self, reps=20) -> float:
         """Average milliseconds of the scan's loads alone over this shard (mtr_index_read_ceiling)."""

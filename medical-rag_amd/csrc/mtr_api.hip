@@ -181,6 +181,7 @@ struct mtr_index {
     hipStream_t last_stream = nullptr;
     bool used = false;
     unsigned char* static_scratch = nullptr;  // this device's copy of the file-scope scratch array
+    const char* last_kernel = "";             // scoring kernel of the last enqueued search
     // profiling
     bool profiling = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -424,6 +425,7 @@ int enqueue_mfma(mtr_index* ix, S& sc, const mtr::MfmaPlan& plan, const void* de
                                         dev_out_score, overflow, stream));
         HIP_TRY(mtr::launch_reset_floors_if(floors, floor_words, overflow, stream));
     }
+    ix->last_kernel = use_wide ? "score_filter_wide_kernel" : "score_topk_mfma_kernel";
     const mtr::MfmaPass all{1, nullptr, overflow, floor_words};
     HIP_TRY(mtr::launch_score_mfma(ix->rows, ix->dtype, ix->n, ix->ld, qbuf, b, k, plan, all, sc.p[kMfmaCand],
                                    floors, lists_s, lists_i, stream));
@@ -469,6 +471,7 @@ int enqueue_search(mtr_index* ix, S& sc, const void* dev_queries, int q_dtype, i
     if ((rc = sc.need(kCandS, (size_t)plan.qb * plan.grid * k * 4)) != MTR_OK) return rc;
     if ((rc = sc.need(kCandI, (size_t)plan.qb * plan.grid * k * 4)) != MTR_OK) return rc;
     if ((rc = sc.ready()) != MTR_OK) return rc;
+    ix->last_kernel = plan.stream_sweeps ? "scan_stream_kernel" : "scan_topk_kernel";
     float* q_f32 = static_cast<float*>(sc.p[kQF32]);
     float* cand_s = static_cast<float*>(sc.p[kCandS]);
     int* cand_i = static_cast<int*>(sc.p[kCandI]);
@@ -906,6 +909,14 @@ int mtr_index_read_ceiling(mtr_index_t* ix, int32_t reps, float* avg_ms) {
     return MTR_OK;
 }
 
+int mtr_index_last_kernel(const mtr_index_t* ix, char* buf, int32_t cap) {
+    int rc = check_index(ix);
+    if (rc != MTR_OK) return rc;
+    if (!buf || cap < 1) return fail(MTR_ERR_INVALID, "buf is NULL or cap < 1");
+    snprintf(buf, (size_t)cap, "%s", ix->last_kernel);
+    return MTR_OK;
+}
+
 void mtr_index_destroy(mtr_index_t* ix) {
     if (!ix) return;
     {
@@ -947,6 +958,9 @@ const TuningField kTuningFields[] = {
     {"mfma_stages", &mtr::Tuning::mfma_stages},           {"mfma_tile_rows", &mtr::Tuning::mfma_tile_rows},
     {"wide_min_batch", &mtr::Tuning::wide_min_batch},     {"wide_qgroup", &mtr::Tuning::wide_qgroup},
     {"scan_wg_per_cu", &mtr::Tuning::scan_wg_per_cu},     {"scan_form", &mtr::Tuning::scan_form},
+    {"scan_static_permille", &mtr::Tuning::scan_static_permille}, {"scan_pair_permille", &mtr::Tuning::scan_pair_permille},
+    {"scan_chunk_groups", &mtr::Tuning::scan_chunk_groups}, {"scan_late_refill", &mtr::Tuning::scan_late_refill},
+    {"scan_mid_permille", &mtr::Tuning::scan_mid_permille},
     {"scan_nontemporal", &mtr::Tuning::scan_nontemporal}, {"scan_max_qb", &mtr::Tuning::scan_max_qb}, {"pool_sliced", &mtr::Tuning::pool_sliced},
 #ifdef MTR_TIMING_SWITCHES
     {"timing_mfma", &mtr::Tuning::timing_mfma},           {"timing_wide", &mtr::Tuning::timing_wide},

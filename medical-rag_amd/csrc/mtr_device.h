@@ -61,6 +61,11 @@ struct Tuning {
     int scan_max_qb = 0;          // most queries per scan pass 1 / 2 / 4 / 8 (0: four)
     int scan_nontemporal = -1;    // -1: streaming row loads on shards beyond the caches; 0 / 1
     int scan_form = 0;            // single-query scan: 0 by shard size; 1 classic form; 2 streaming form wherever the shape allows
+    int scan_static_permille = 0; // streaming form: share of the row groups the waves take by index (0: 880) ...
+    int scan_chunk_groups = 0;    // ... groups per claimed chunk of a first phase (0: one) ...
+    int scan_mid_permille = 0;    // ... which runs up to here (0: no such phase); chunks of two groups follow ...
+    int scan_pair_permille = 0;   // ... up to here (0: none either), single groups after
+    int scan_late_refill = 0;     // from this share of the groups on, one group per wave, claimed on demand (0: 985; -1: never)
     int pool_sliced = -1;         // pooling kernel form: -1 by shape (two kernels from 256 tokens); 0 one kernel; 1 two kernels
     int timing_mfma = 0;          // MTR_TIMING_SWITCHES builds only: drop candidates / skip loads or MFMAs (wrong results)
     int timing_wide = 0;          // MTR_TIMING_SWITCHES builds only

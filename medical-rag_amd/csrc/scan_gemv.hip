@@ -368,9 +368,12 @@ __global__ __launch_bounds__(waves_per_group(1) * 64) void scan_read_only_kernel
 // counter takes about one claim per 5 ns) and are made by a fifth wave of the
 // workgroup, which does nothing else: an atomic with return sits in its wave's
 // queue of loads, which return in order, so in a scanning wave a slow claim
-// would hold back the rows requested behind it.  The claimer keeps one claimed
-// chunk per scanning wave in an LDS box; a wave that empties its box finds it
-// refilled by the time it has scanned the chunk.
+// would hold back the rows requested behind it.  The claimer keeps up to three
+// claimed chunks per scanning wave in LDS boxes; a wave takes them in turn and
+// stops once all hold a slot past the end.  Every claim costs the whole chip
+// about 1.5 ns (all claims go to one address, so to one memory channel, which
+// every scanning wave needs as well), so the claimer refills boxes four at a
+// time with one atomic, or earlier when a wave is down to its last chunk.
 //
 // The scanning loop takes two units (a unit = SWEEPS sweeps of a group's four
 // row quads) per trip, one per register set, and requests a unit before it
@@ -387,20 +390,34 @@ __global__ __launch_bounds__(waves_per_group(1) * 64) void scan_read_only_kernel
 constexpr int kStreamWaves = 4;                     // scanning waves; one more wave claims chunks for them
 constexpr int kStreamThreads = (kStreamWaves + 1) * 64;
 constexpr unsigned int kBoxEmpty = 0xffffffffu;
+constexpr unsigned int kBoxPastEnd = 0xfffffffeu;   // a slot past the end of any shard
+constexpr unsigned long long kStreamGiveUpTicks = 2000000000ull;   // 20 s of the 100 MHz wall clock
+constexpr int kBoxDepth = 3;                        // claimed chunks kept ready per scanning wave
 constexpr int kStreamQuads = 4;                     // 16 rows per group
 constexpr int kStreamGroupRows = 4 * kStreamQuads;
 
+constexpr int kStreamPhases = 3;
 struct StreamSplit {
     long long ngroups;          // groups of 16 rows
     long long static_groups;    // groups every wave takes by its index (wave w: w, w + W, ...)
     long long dyn_first;        // first group of the claimed part = static_groups * W
-    long long pairs;            // chunks of two groups at the start of the claimed part; single groups follow
+    // The claimed part: phase p hands out slots[p] chunks of chunk[p] groups; the
+    // chunks shrink towards the end (the last phase is single groups, as many as are left).
+    long long slots[kStreamPhases];
+    int chunk[kStreamPhases];
+    long long late_from;        // from this slot on: one box per wave, refilled on demand
     unsigned int* sync;         // [0] claim counter, [16] workgroups whose claimer has finished; both zero between launches
 };
 
 __device__ __forceinline__ bool stream_chunk(const StreamSplit& sp, long long slot, long long& g0, long long& g1) {
-    if (slot < sp.pairs) { g0 = sp.dyn_first + 2 * slot; g1 = g0 + 2; return true; }
-    g0 = sp.dyn_first + 2 * sp.pairs + (slot - sp.pairs);
+    long long first = sp.dyn_first;
+#pragma unroll
+    for (int p = 0; p < kStreamPhases - 1; ++p) {
+        if (slot < sp.slots[p]) { g0 = first + sp.chunk[p] * slot; g1 = g0 + sp.chunk[p]; return true; }
+        slot -= sp.slots[p];
+        first += sp.chunk[p] * sp.slots[p];
+    }
+    g0 = first + slot;
     g1 = g0 + 1;
     return g0 < sp.ngroups;
 }
@@ -520,7 +537,7 @@ __global__ __launch_bounds__(kStreamThreads) void scan_stream_kernel(ScanArgs a,
     float* list_s = q_lds + a.qstride;
     int* list_i = reinterpret_cast<int*>(list_s + kStreamWaves * a.k);
     int* cnt_lds = list_i + kStreamWaves * a.k;
-    unsigned int* box = reinterpret_cast<unsigned int*>(cnt_lds + kStreamWaves);   // one claimed slot per scanning wave
+    unsigned int* box = reinterpret_cast<unsigned int*>(cnt_lds + kStreamWaves);   // [wave][kBoxDepth] claimed slots
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -528,18 +545,46 @@ __global__ __launch_bounds__(kStreamThreads) void scan_stream_kernel(ScanArgs a,
     constexpr int kFoldBarriers = ARITH ? 4 : 0;   // two per halving round of the final fold
 
     if (wave == kStreamWaves) {
-        // ---- the claimer: lane l keeps the box of scanning wave l filled ----
-        if (lane < kStreamWaves) box[lane] = kBoxEmpty;
+        // ---- the claimer: lane l keeps box l (wave l / kBoxDepth) filled ----
+        constexpr int kBoxes = kStreamWaves * kBoxDepth;
+        if (lane < kBoxes) box[lane] = kBoxEmpty;
         __syncthreads();
-        bool finished = lane >= kStreamWaves;   // ... until it has handed it a slot past the end
+        bool finished = lane >= kBoxes;   // ... until it has put a slot past the end into it
+        const int my_wave_shift = (lane / kBoxDepth) * kBoxDepth;
+        constexpr unsigned long long kWaveBoxes = (1ull << kBoxDepth) - 1;
+        const unsigned long long give_up_at = wall_clock64() + kStreamGiveUpTicks;
+        bool late = false;   // wave-uniform: the single groups at the end are being handed out
         while (__ballot(!finished) != 0ull) {
-            if (!finished && __hip_atomic_load(&box[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == kBoxEmpty) {
+            const bool empty =
+                !finished && __hip_atomic_load(&box[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == kBoxEmpty;
+            const unsigned long long empties = __ballot(empty);
+            const unsigned long long ready = __ballot(!empty && !finished);   // boxes that hold a chunk
+            const int my_ready = __popcll((ready >> my_wave_shift) & kWaveBoxes);
+            const unsigned long long my_empties = (empties >> my_wave_shift) & kWaveBoxes;
+            bool fill;
+            if (!late) {
+                // Boxes are refilled four at a time, or at once for a wave with at most one chunk left.
+                const bool low = lane < kBoxes && my_ready <= 1 && my_empties != 0;
+                fill = empty && (__popcll(empties) >= kStreamWaves || __ballot(low) != 0ull);
+            } else {
+                // Near the end a chunk queued behind a slow wave is a chunk a fast wave could have
+                // scanned: one box per wave, refilled when the wave starts on its chunk.
+                fill = empty && my_ready == 0 && lane - my_wave_shift == __ffsll((long long)my_empties) - 1;
+            }
+            if (fill) {
+                // (one atomic for all the lanes that claim: the compiler adds their count and hands out the slots)
                 const unsigned int slot = __hip_atomic_fetch_add(sp.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&box[lane], slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 long long c0, c1;
                 finished = !stream_chunk(sp, (long long)slot, c0, c1);
+                if ((long long)slot >= sp.late_from) late = true;
             }
-            __builtin_amdgcn_s_sleep(16);
+            late = __ballot(late) != 0ull;
+            __builtin_amdgcn_s_sleep(8);
+            if (wall_clock64() > give_up_at) {   // never in a working launch: keeps a fault elsewhere from hanging the GPU
+                if (lane < kBoxes) box[lane] = kBoxPastEnd;
+                break;
+            }
         }
         // This workgroup claims nothing more; the last claimer of the launch to get
         // here leaves both counters at zero for the next launch.
@@ -564,6 +609,7 @@ __global__ __launch_bounds__(kStreamThreads) void scan_stream_kernel(ScanArgs a,
     long long g = wid, g_end = wid + 1, j_static = 0;
     int s0 = 0;
     bool valid = sp.static_groups > 0;   // the launcher only picks this form for shards with many groups per wave
+    int box_turn = 0;
     auto advance = [&]() {
         if (!valid) return;
         s0 += SWEEPS;
@@ -572,18 +618,32 @@ __global__ __launch_bounds__(kStreamThreads) void scan_stream_kernel(ScanArgs a,
         g += 1;
         if (g < g_end) return;
         if (++j_static < sp.static_groups) { g = wid + j_static * W; g_end = g + 1; return; }
-        // the chunk the claimer has put into this wave's box (refilled while the chunk is scanned)
-        unsigned int slot;
-        while ((slot = (unsigned int)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(
-                    &box[wave], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) == kBoxEmpty)
-            __builtin_amdgcn_s_sleep(1);
-        long long c0, c1;
-        if (stream_chunk(sp, (long long)slot, c0, c1)) {
-            g = c0; g_end = c1;
-            if (lane == 0) __hip_atomic_store(&box[wave], kBoxEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        } else {
-            valid = false;   // slots are handed out in order: every later one is past the end too
+        // The next claimed chunk from this wave's boxes: the first one, from the box
+        // after the last one taken, that holds a chunk.  The wave is done when every
+        // box holds a slot past the end; while some box is empty it waits for the
+        // claimer (which refills at once when a wave has nothing left).
+        const unsigned long long give_up_at = wall_clock64() + kStreamGiveUpTicks;
+        for (;;) {
+            int past_end = 0;
+            for (int t = 0; t < kBoxDepth; ++t) {
+                const int bi = (box_turn + t) % kBoxDepth;
+                unsigned int* my_box = box + wave * kBoxDepth + bi;
+                const unsigned int slot = (unsigned int)__builtin_amdgcn_readfirstlane(
+                    (int)__hip_atomic_load(my_box, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                if (slot == kBoxEmpty) continue;
+                long long c0, c1;
+                if (stream_chunk(sp, (long long)slot, c0, c1)) {
+                    g = c0; g_end = c1;
+                    box_turn = (bi + 1) % kBoxDepth;
+                    if (lane == 0) __hip_atomic_store(my_box, kBoxEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    return;
+                }
+                ++past_end;
+            }
+            if (past_end == kBoxDepth || wall_clock64() > give_up_at) break;
+            __builtin_amdgcn_s_sleep(2);
         }
+        valid = false;
     };
 
     u32x4 ra[SWEEPS][kStreamQuads], rb[SWEEPS][kStreamQuads];
@@ -682,7 +742,7 @@ __global__ __launch_bounds__(kStreamThreads) void scan_stream_kernel(ScanArgs a,
 }
 
 size_t stream_lds_bytes(int qstride, int k) {
-    return (size_t)qstride * 4 + (size_t)kStreamWaves * k * 8 + (size_t)kStreamWaves * 4 + (size_t)kStreamWaves * 4;
+    return (size_t)qstride * 4 + (size_t)kStreamWaves * k * 8 + (size_t)kStreamWaves * 4 + (size_t)kStreamWaves * kBoxDepth * 4;
 }
 
 // Sweeps per unit: the largest of 4, 3, 2 that divides the sweeps of a row (a
@@ -693,12 +753,45 @@ StreamSplit stream_split(int64_t n, int grid, unsigned int* sync) {
     StreamSplit sp;
     const long long W = (long long)grid * kStreamWaves;
     sp.ngroups = (n + kStreamGroupRows - 1) / kStreamGroupRows;
-    // 96 % of the groups by index; of the rest, pairs up to 99.5 %, then single groups: on
-    // 10M x 2048 B about 16 K claims, which the counter takes without queueing
-    sp.static_groups = (long long)(0.96 * (double)sp.ngroups) / W;
+    // 88 % of the groups by index, the rest claimed group by group, the last 1.5 % on demand.  (Larger chunks would
+    // save claims, but a wave that streams a stretch of its own reads slower than waves
+    // that sweep neighbouring groups together: 10M x 2048 B, a quarter of the rows claimed,
+    // chunks of 4 / 8 / 16 groups: 2.868 / 2.873 / 2.896 ms.  The phases remain for sweeps:
+    // tuning scan_static_permille, scan_chunk_groups up to scan_mid_permille, pairs up to
+    // scan_pair_permille.)
+    const double f_static = tuning().scan_static_permille > 0 ? tuning().scan_static_permille * 1e-3 : 0.88;
+    const double f_mid = tuning().scan_mid_permille > 0 ? tuning().scan_mid_permille * 1e-3 : 0.0;
+    const double f_pairs = tuning().scan_pair_permille > 0 ? tuning().scan_pair_permille * 1e-3 : 0.0;
+    sp.static_groups = (long long)(f_static * (double)sp.ngroups) / W;
+    if (sp.static_groups < 1) sp.static_groups = 1;
     sp.dyn_first = sp.static_groups * W;
-    const long long pair_end = (long long)(0.995 * (double)sp.ngroups);
-    sp.pairs = pair_end > sp.dyn_first ? (pair_end - sp.dyn_first) / 2 : 0;
+    sp.chunk[0] = tuning().scan_chunk_groups > 0 ? tuning().scan_chunk_groups : 1;
+    sp.chunk[1] = 2;
+    sp.chunk[2] = 1;
+    long long at = sp.dyn_first;
+    const long long mid_end = (long long)(f_mid * (double)sp.ngroups);
+    sp.slots[0] = mid_end > at ? (mid_end - at) / sp.chunk[0] : 0;
+    at += sp.slots[0] * sp.chunk[0];
+    const long long pair_end = (long long)(f_pairs * (double)sp.ngroups);
+    sp.slots[1] = pair_end > at ? (pair_end - at) / sp.chunk[1] : 0;
+    sp.slots[2] = 0;   // the last phase runs to the end
+    // scan_late_refill: the share of the groups (per mille) from which on a wave is handed one
+    // group at a time, on demand (0: 985; -1: never)
+    sp.late_from = 0x7fffffffll;
+    const int late_permille = tuning().scan_late_refill > 0 ? tuning().scan_late_refill : tuning().scan_late_refill < 0 ? 0 : 985;
+    if (late_permille > 0) {
+        const long long late_group = (long long)(late_permille * 1e-3 * (double)sp.ngroups);
+        // slots before late_group, with the phases' chunk sizes
+        long long slot = 0, first = sp.dyn_first;
+        for (int p = 0; p < kStreamPhases; ++p) {
+            const long long n_p = p < kStreamPhases - 1 ? sp.slots[p] : sp.ngroups;
+            const long long last = first + n_p * sp.chunk[p];
+            if (late_group < last) { slot += late_group > first ? (late_group - first) / sp.chunk[p] : 0; break; }
+            slot += n_p;
+            first = last;
+        }
+        sp.late_from = slot;
+    }
     sp.sync = sync;
     return sp;
 }

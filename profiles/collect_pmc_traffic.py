@@ -10,14 +10,14 @@ import subprocess
 import sys
 
 STEPS, WARMUP = 3, 1
-KERNEL = {"c4": "scan_topk_kernel", "c2": "scan_topk_kernel", "c3": "score_"}  # c3: sampling launch (score_topk_mfma_kernel) + score_filter_wide_kernel
+KERNEL = {"c4": "scan_", "c2": "scan_", "c3": "score_"}  # scan_stream_kernel on these shards (scan_topk_kernel under MTR_SCAN_FORM=1);  # c3: sampling launch (score_topk_mfma_kernel) + score_filter_wide_kernel
 out = {}
 for wl, kern in KERNEL.items():
     vals = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         tag = f"{wl}_{counter.lower()}"
         subprocess.run(["bash", "profiles/pmc_pass.sh", tag, counter, kern, "--workload", wl, "--steps", str(STEPS),
-                        "--warmup", str(WARMUP), "--no-cpu-baseline"], check=True, stdout=subprocess.DEVNULL)
+                        "--warmup", str(WARMUP), "--no-cpu-baseline", "--no-ceiling"], check=True, stdout=subprocess.DEVNULL)
         vals[counter] = json.load(open(f"gpurun_out/pmc/{tag}.json"))[counter]
     searches = STEPS + WARMUP
     fetch = vals["FETCH_SIZE"]["sum"] / searches
