@@ -254,25 +254,54 @@ __global__ void merge_select_kernel(MergeArgs a) {
             __builtin_amdgcn_wave_barrier();
             staged = 0;
         };
-        for (int l = wave; l < a.n_lists; l += nwaves) {
-            const size_t slot0 = (((size_t)(q >> 8) * groups + l / a.key_subs) * 256 + (q & 255)) * a.key_subs + l % a.key_subs;
-            unsigned int have = a.key_counts[slot0];
-            if (have > (unsigned int)a.k_in) {
-                if (lane == 0) *a.overflow = 1;
-                have = (unsigned int)a.k_in;
+        // Most lists are empty or hold a key or two (a query's hits are spread over
+        // thousands of lists), so the lists are taken 64 at a time, one per lane: the
+        // counts with one load, the first two keys of every list with one load each,
+        // compacted behind the survivors; only longer lists are then walked one by one.
+        auto slot_of = [&](int l) {
+            return (((size_t)(q >> 8) * groups + l / a.key_subs) * 256 + (q & 255)) * a.key_subs + l % a.key_subs;
+        };
+        auto stage_key = [&](unsigned long long raw) {
+            const int row = (int)(unsigned int)raw;
+            return row < a.key_rows ? pack_key(__uint_as_float((unsigned int)(raw >> 32)), row) : 0ull;
+        };
+        constexpr int kDirect = 2;
+        for (int l0 = wave; l0 < a.n_lists; l0 += nwaves * 64) {
+            const int my_l = l0 + lane * nwaves;
+            unsigned int my_have = 0;
+            size_t my_slot0 = 0;
+            if (my_l < a.n_lists) {
+                my_slot0 = slot_of(my_l);
+                my_have = a.key_counts[my_slot0];
             }
-            const unsigned long long* src = a.keys + slot0 * a.k_in;
-            int done = 0;
-            while (done < (int)have) {
-                const int take = (int)have - done < chunk - staged ? (int)have - done : chunk - staged;
-                for (int j = lane; j < take; j += 64) {
-                    const unsigned long long raw = src[done + j];  // row | score bits << 32
-                    const int row = (int)(unsigned int)raw;
-                    my_list[k + staged + j] = row < a.key_rows ? pack_key(__uint_as_float((unsigned int)(raw >> 32)), row) : 0ull;
+            if (my_have > (unsigned int)a.k_in) {
+                *a.overflow = 1;
+                my_have = (unsigned int)a.k_in;
+            }
+            if (__ballot(my_have != 0) == 0ull) continue;
+#pragma unroll
+            for (int t = 0; t < kDirect; ++t) {
+                const bool has = my_have > (unsigned int)t;
+                const unsigned long long mask = __ballot(has);
+                if (mask == 0ull) break;
+                if (staged + 64 > chunk) select_round();
+                if (has) my_list[k + staged + __popcll(mask & ((1ull << lane) - 1ull))] = stage_key(a.keys[my_slot0 * a.k_in + t]);
+                staged += __popcll(mask);
+            }
+            unsigned long long longer = __ballot(my_have > (unsigned int)kDirect);
+            while (longer) {
+                const int j = __ffsll((long long)longer) - 1;
+                longer &= longer - 1;
+                const int have = __builtin_amdgcn_readlane((int)my_have, j);
+                const unsigned long long* src = a.keys + slot_of(l0 + j * nwaves) * a.k_in;
+                int done = kDirect;
+                while (done < have) {
+                    if (staged == chunk) select_round();
+                    const int take = have - done < chunk - staged ? have - done : chunk - staged;
+                    for (int i = lane; i < take; i += 64) my_list[k + staged + i] = stage_key(src[done + i]);
+                    staged += take;
+                    done += take;
                 }
-                staged += take;
-                done += take;
-                if (staged == chunk) select_round();
             }
         }
         if (staged > 0) select_round();
