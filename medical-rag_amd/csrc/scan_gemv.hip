@@ -368,12 +368,15 @@ __global__ __launch_bounds__(waves_per_group(1) * 64) void scan_read_only_kernel
 // counter takes about one claim per 5 ns) and are made by a fifth wave of the
 // workgroup, which does nothing else: an atomic with return sits in its wave's
 // queue of loads, which return in order, so in a scanning wave a slow claim
-// would hold back the rows requested behind it.  The claimer keeps up to three
+// would hold back the rows requested behind it.  The claimer keeps up to two
 // claimed chunks per scanning wave in LDS boxes; a wave takes them in turn and
 // stops once all hold a slot past the end.  Every claim costs the whole chip
 // about 1.5 ns (all claims go to one address, so to one memory channel, which
 // every scanning wave needs as well), so the claimer refills boxes four at a
-// time with one atomic, or earlier when a wave is down to its last chunk.
+// time with one atomic, or at once for a wave that has none left.  Deeper boxes
+// are no better (three or four per wave, refilled eight or sixteen at a time:
+// +0.1 to +0.7 % of the scan's time): groups claimed long before they are read
+// widen the stretch of memory the chip reads at any one time.
 //
 // The scanning loop takes two units (a unit = SWEEPS sweeps of a group's four
 // row quads) per trip, one per register set, and requests a unit before it
@@ -392,7 +395,9 @@ constexpr int kStreamThreads = (kStreamWaves + 1) * 64;
 constexpr unsigned int kBoxEmpty = 0xffffffffu;
 constexpr unsigned int kBoxPastEnd = 0xfffffffeu;   // a slot past the end of any shard
 constexpr unsigned long long kStreamGiveUpTicks = 2000000000ull;   // 20 s of the 100 MHz wall clock
-constexpr int kBoxDepth = 3;                        // claimed chunks kept ready per scanning wave
+constexpr int kBoxDepth = 2;                        // claimed chunks kept ready per scanning wave
+constexpr int kLowReady = 0;                        // a wave with this many chunks left (or fewer) is refilled at once
+constexpr int kRefillEmpties = kStreamWaves * (kBoxDepth > 2 ? kBoxDepth - 2 : 1);   // empty boxes that make a refill worth an atomic
 constexpr int kStreamQuads = 4;                     // 16 rows per group
 constexpr int kStreamGroupRows = 4 * kStreamQuads;
 
@@ -564,8 +569,8 @@ __global__ __launch_bounds__(kStreamThreads) void scan_stream_kernel(ScanArgs a,
             bool fill;
             if (!late) {
                 // Boxes are refilled four at a time, or at once for a wave with at most one chunk left.
-                const bool low = lane < kBoxes && my_ready <= 1 && my_empties != 0;
-                fill = empty && (__popcll(empties) >= kStreamWaves || __ballot(low) != 0ull);
+                const bool low = lane < kBoxes && my_ready <= kLowReady && my_empties != 0;
+                fill = empty && (__popcll(empties) >= kRefillEmpties || __ballot(low) != 0ull);
             } else {
                 // Near the end a chunk queued behind a slow wave is a chunk a fast wave could have
                 // scanned: one box per wave, refilled when the wave starts on its chunk.
