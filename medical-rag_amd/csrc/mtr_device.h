@@ -55,6 +55,7 @@ struct Tuning {
     int mfma_stream_rows = -1;    // -1: streaming row loads when one query tile reads a shard beyond the caches; 0 / 1
     int mfma_stages = 0;          // LDS stage buffers 2 / 3 (0: by form)
     int mfma_tile_rows = 0;       // rows per tile 128 / 256 (0: by form)
+    int mfma_interleave = -1;     // -1: ranges interleaved tile by tile when one query tile streams a large shard; 0 / 1
     int wide_min_batch = 129;     // smallest batch for the 256 x 256-tile kernel
     int wide_qgroup = 0;          // its query tiles per row list on one XCD (0: four)
     int scan_wg_per_cu = 0;       // scan workgroups per CU (0: one for a single query, occupancy otherwise)
@@ -163,6 +164,7 @@ struct MfmaPlan {
     size_t cand_bytes;        // scratch for the workgroups' candidate buffers
     int stream_rows;          // row tiles loaded with the streaming (nt) cache policy
     int stages;               // LDS stage buffers: 2, or 3 (ring with counted waits)
+    int interleave;           // row ranges interleaved tile by tile instead of contiguous stretches
 };
 
 // Launch shape of the matrix-core scoring kernel; -1 when the shape is not

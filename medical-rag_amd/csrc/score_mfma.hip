@@ -95,6 +95,7 @@ struct MfmaArgs {
     float* out_s;            // [b][n_ranges][k]
     int* out_i;
     const int* run_if;       // not NULL: do nothing while *run_if == 0
+    int interleave;          // 1: range r takes tiles r, r + n_ranges, ... instead of a contiguous stretch (tile_stride 1 only)
 };
 
 template <int AUX, int ROWS, int WAVES>
@@ -484,13 +485,17 @@ __global__ __launch_bounds__(TM == 256 ? 512 : 256, TM == 256 ? 1 : 2) void scor
     const int range = wgid % a.n_ranges;
 
     const long long n_tiles = a.n_tiles;
-    const long long tile_lo = (long long)range * a.tiles_per_range;
+    long long tile_lo = (long long)range * a.tiles_per_range;
     long long tile_hi = tile_lo + a.tiles_per_range;
     if (tile_hi > n_tiles) tile_hi = n_tiles;
-    const long long my_tiles = tile_hi > tile_lo ? tile_hi - tile_lo : 0;
+    long long my_tiles = tile_hi > tile_lo ? tile_hi - tile_lo : 0;
+    if (a.interleave) {   // the ranges sweep the matrix side by side: tiles range, range + n_ranges, ...
+        tile_lo = 0;
+        my_tiles = range < n_tiles ? (n_tiles - range + a.n_ranges - 1) / a.n_ranges : 0;
+    }
     const int ksteps = a.ld / BK;
     // Tile t of this launch is tile phys(t) of the matrix (increasing in t).
-    auto phys = [&](long long t) -> long long { return t * a.tile_stride; };
+    auto phys = [&](long long t) -> long long { return a.interleave ? t * a.n_ranges + range : t * a.tile_stride; };
     unsigned int* best_lds = reinterpret_cast<unsigned int*>(cnt_lds);  // max_only: best score of the tile per query
     const long long row_bytes = (long long)a.ld * (long long)sizeof(T);
 
@@ -782,6 +787,9 @@ int plan_mfma(int dtype, int64_t n, int ld, int b, int k, int num_cus, int sampl
     plan->tiles_per_range = (n_tiles + ranges - 1) / ranges;
     plan->n_ranges = (int)((n_tiles + plan->tiles_per_range - 1) / plan->tiles_per_range);
     plan->grid = plan->n_qtiles * plan->n_ranges;
+    // One query tile streaming a large shard: the workgroups sweep the rows side by side.
+    plan->interleave = (plan->stream_rows && plan->n_qtiles == 1) ? 1 : 0;
+    if (tn.mfma_interleave >= 0) plan->interleave = !sampling && tn.mfma_interleave != 0;
     plan->lds = lds_bytes(tm, plan->tnq, plan->stages);
     plan->cand_bytes = (size_t)plan->grid * plan->tnq * plan->cap * 8;
     return 0;
@@ -827,6 +835,7 @@ hipError_t launch_score_mfma(const void* rows, int dtype, int64_t n, int ld, con
     a.out_s = out_s;
     a.out_i = out_i;
     a.run_if = pass.run_if;
+    a.interleave = plan.interleave && a.tile_stride == 1 && a.tile_max == nullptr;
     auto launch = [&](auto kernel) -> hipError_t {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds);

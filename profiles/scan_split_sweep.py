@@ -3,7 +3,8 @@
 switches, interleaved over several rounds on ONE box (devices and runs differ
 by a per cent, so settings are only comparable side by side): per-launch HIP
 event time of the scan kernel.
-usage: scan_split_sweep.py rows dim [bf16|fp32] [reps] -- name=value,name=value ...   (one group per setting)"""
+usage: scan_split_sweep.py rows dim [bf16|fp32] [reps [batch [k]]] -- name=value,name=value ...   (one group per setting;
+"default" = no switch set)"""
 import json
 import sys
 
@@ -19,26 +20,31 @@ def main():
     rows, dim = int(args[0]), int(args[1])
     store = args[2] if cut > 2 else "bf16"
     reps = int(args[3]) if cut > 3 else 20
-    settings = [dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in grp.split(",") if kv) for grp in args[cut + 1:]]
+    batch = int(args[4]) if cut > 4 else 1
+    k = int(args[5]) if cut > 5 else 10
+    settings = [dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in grp.split(",") if kv and kv != "default")
+                for grp in args[cut + 1:]]
     gen = torch.Generator(device="cuda").manual_seed(7)
     shard = native.DeviceShard.alloc(rows, dim, store_dtype=store)
     for r0 in range(0, rows, 262144):
         n = min(262144, rows - r0)
         shard.load_device(r0, torch.randn((n, dim), generator=gen, device="cuda"))
-    q = torch.randn((1, dim), generator=gen, device="cuda")
+    q = torch.randn((batch, dim), generator=gen, device="cuda")
     times = [[] for _ in settings]
     ids = []
+    kernels = []
     for rnd in range(4):
         for si, st in enumerate(settings):
             with native.options(**st):
                 for _ in range(3):
-                    out = shard.search_device(q, k=10)
+                    out = shard.search_device(q, k=k)
                 torch.cuda.synchronize()
                 if rnd == 0:
                     ids.append(out[0].clone())
+                    kernels.append(shard.last_kernel())
                 shard.profile(True)
                 for _ in range(reps):
-                    shard.search_device(q, k=10)
+                    shard.search_device(q, k=k)
                 torch.cuda.synchronize()
                 n, ms = shard.scan_time()
                 shard.profile(False)
@@ -46,7 +52,7 @@ def main():
     nbytes = rows * dim * (2 if store == "bf16" else 4)   # the widths used here need no padding
     for st, t in zip(settings, times):
         best = min(t)
-        print(json.dumps({"rows": rows, "dim": dim, "store": store, "setting": st, "kernel_ms": [round(x, 4) for x in t],
+        print(json.dumps({"rows": rows, "dim": dim, "store": store, "batch": batch, "k": k, "kernel": kernels[settings.index(st)], "setting": st, "kernel_ms": [round(x, 4) for x in t],
                           "min_ms": round(best, 4), "GBps_at_min": round(nbytes / best / 1e6, 1),
                           "same_ids_as_first": bool(torch.equal(ids[0], ids[settings.index(st)]))}))
 
