@@ -459,6 +459,140 @@ __global__ __launch_bounds__(kHeadsThreads) void merge_heads_kernel(MergeArgs a)
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// Long result lists (256 < k <= 1024) from up to 16 K candidates with 32-bit
+// ids: one workgroup of 1024 threads per query holds every candidate key in
+// registers, finds the k-th largest with a radix walk over the whole
+// workgroup (eight 8-bit digits, an LDS histogram per digit), compacts the k
+// survivors into LDS and orders them by rank counting over LDS broadcast
+// reads.  The streaming merge above inserts nearly every candidate into lists
+// of k entries (0.4 ms for 8 K candidates and k = 1024); this takes 20 us.
+// ---------------------------------------------------------------------------
+constexpr int kRadixThreads = 1024;
+
+template <int E>
+__global__ __launch_bounds__(kRadixThreads) void merge_radix_kernel(MergeArgs a) {
+    if (a.run_if && *a.run_if == 0) return;
+    __shared__ unsigned int hist[256];
+    __shared__ unsigned int state[4];               // [0] bin picked, [1] candidates still wanted from it, [2] survivors
+    __shared__ unsigned long long surv[1024];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int q = blockIdx.x;
+    const long long qbase = (long long)q * a.query_stride;
+    const int total = a.n_lists * a.k_in;
+    const int k = a.k_out;
+
+    unsigned long long key[E];
+    bool act[E];
+    int mine = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = e * kRadixThreads + tid;
+        key[e] = 0ull;
+        if (i < total) {
+            const int l = i / a.k_in, j = i - l * a.k_in;
+            const int id = a.ci32[l * a.list_stride + qbase + j];
+            if (id >= 0) key[e] = pack_key(a.cs[l * a.list_stride_s + qbase + j], id);
+        }
+        act[e] = key[e] != 0ull;
+        mine += act[e] ? 1 : 0;
+    }
+    if (tid < 4) state[tid] = 0u;
+    __syncthreads();
+    if (mine) atomicAdd(&state[2], (unsigned int)mine);
+    __syncthreads();
+    const int have = (int)state[2];
+    __syncthreads();
+
+    unsigned long long cut = 0ull;   // have <= k: every candidate survives
+    if (have > k) {
+        int need = k;
+        unsigned long long prefix = 0ull;
+        for (int pass = 0; pass < 8; ++pass) {
+            const int shift = 56 - 8 * pass;
+            if (tid < 256) hist[tid] = 0u;
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+                if (act[e]) atomicAdd(&hist[(unsigned int)(key[e] >> shift) & 255u], 1u);
+            __syncthreads();
+            if (tid < 64) {   // wave 0: lane l looks after bins 4l .. 4l+3; higher bins hold larger keys
+                const unsigned int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+                const unsigned int sum = h0 + h1 + h2 + h3;
+                unsigned int incl = sum;   // inclusive sum over lanes >= this one
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const unsigned int t = __shfl_down(incl, off, 64);
+                    if (lane + off < 64) incl += t;
+                }
+                const unsigned int a3 = incl - sum, a2 = a3 + h3, a1 = a2 + h2, a0 = a1 + h1;
+                const unsigned int un = (unsigned int)need;
+                if (a3 < un && un <= a3 + h3) { state[0] = 4 * lane + 3; state[1] = un - a3; }
+                else if (a2 < un && un <= a2 + h2) { state[0] = 4 * lane + 2; state[1] = un - a2; }
+                else if (a1 < un && un <= a1 + h1) { state[0] = 4 * lane + 1; state[1] = un - a1; }
+                else if (a0 < un && un <= a0 + h0) { state[0] = 4 * lane; state[1] = un - a0; }
+            }
+            __syncthreads();
+            const unsigned int bin = state[0];
+            need = (int)state[1];
+            prefix |= (unsigned long long)bin << shift;
+#pragma unroll
+            for (int e = 0; e < E; ++e) act[e] = act[e] && (((unsigned int)(key[e] >> shift) & 255u) == bin);
+            __syncthreads();
+        }
+        cut = prefix;   // keys are unique: the walk ends on the k-th largest key itself
+    }
+    if (tid == 0) state[2] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+        if (key[e] != 0ull && key[e] >= cut) {
+            const unsigned int slot = atomicAdd(&state[2], 1u);
+            if (slot < 1024u) surv[slot] = key[e];
+        }
+    __syncthreads();
+    const int c = (int)(state[2] < 1024u ? state[2] : 1024u);
+    float* os = a.out_s + (size_t)q * k;
+    long long* oi = a.out_i + (size_t)q * k;
+    if (tid < c) {
+        const unsigned long long me = surv[tid];
+        int rank = 0;
+        for (int o = 0; o < c; ++o) rank += surv[o] > me ? 1 : 0;   // LDS broadcast reads
+        if (rank < k) {
+            os[rank] = key_score(me);
+            oi[rank] = (long long)key_row(me) + a.idx_offset;
+        }
+    }
+    for (int i = c + tid; i < k; i += kRadixThreads) {
+        os[i] = -__builtin_huge_valf();
+        oi[i] = -1ll;
+    }
+}
+
+// Were the lists long enough?  A scan may keep fewer than k_out candidates per
+// list (k_in < k_out: a list's share of a query's k_out best rows is small when
+// the rows are dealt evenly).  The merged result is then exact unless some full
+// list's LAST kept entry beats the merged k_out-th entry: only then can a row
+// the list dropped (all of them rank below its last kept entry) belong to the
+// result.  Raises *flag in that case; the caller re-runs the search with full
+// lists behind it.
+__global__ void check_short_lists_kernel(const float* cand_s, const int* cand_i, int n_lists, long long list_stride,
+                                         long long query_stride, int k_in, int k_out, long long idx_offset,
+                                         const long long* out_idx, const float* out_score, int* flag) {
+    const int q = blockIdx.x;
+    const long long gk_i = out_idx[(size_t)q * k_out + k_out - 1];
+    const float gk_s = out_score[(size_t)q * k_out + k_out - 1];
+    for (int l = threadIdx.x; l < n_lists; l += blockDim.x) {
+        const long long at = (long long)l * list_stride + (long long)q * query_stride + k_in - 1;
+        const int id = cand_i[at];
+        if (id < 0) continue;   // the list is not full: it dropped nothing
+        const float s = cand_s[at];
+        if (gk_i < 0 || s > gk_s || (s == gk_s && (long long)id + idx_offset < gk_i)) *flag = 1;
+    }
+}
+
 }  // namespace
 
 hipError_t launch_merge_sorted_lists(const float* cand_s, const int* idx32, int n_lists, long long list_stride,
@@ -491,11 +625,25 @@ hipError_t launch_merge_topk(const float* cand_s, const int* idx32, const long l
         hipLaunchKernelGGL(merge_select_kernel, dim3(b), dim3(nw * 64), lds_sel, stream, a);
         return hipGetLastError();
     }
+    if (idx32 && k_out <= 1024 && total <= 16 * kRadixThreads && total > 2 * k_out) {
+        if (total <= 8 * kRadixThreads) hipLaunchKernelGGL(merge_radix_kernel<8>, dim3(b), dim3(kRadixThreads), 0, stream, a);
+        else hipLaunchKernelGGL(merge_radix_kernel<16>, dim3(b), dim3(kRadixThreads), 0, stream, a);
+        return hipGetLastError();
+    }
     int nwaves = 16;
     while (nwaves > 1 && (long long)nwaves * 64 * 2 > total) nwaves /= 2;            // no idle waves on short inputs
     while (nwaves > 1 && (size_t)nwaves * k_out * 12 + kQueueCap * 12 + 128 > 60 * 1024) nwaves /= 2;  // LDS budget
     const size_t lds = (size_t)nwaves * k_out * 12 + (size_t)kQueueCap * 12 + (size_t)nwaves * 4 + 16;
     hipLaunchKernelGGL(merge_topk_kernel, dim3(b), dim3(nwaves * 64), lds, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_check_short_lists(const float* cand_s, const int* cand_i, int n_lists, long long list_stride,
+                                    long long query_stride, int k_in, int b, int k_out, long long idx_offset,
+                                    const long long* out_idx, const float* out_score, int* flag, hipStream_t stream) {
+    if (b < 1 || n_lists < 1 || k_in < 1 || k_out < 1 || !flag) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(check_short_lists_kernel, dim3(b), dim3(256), 0, stream, cand_s, cand_i, n_lists, list_stride,
+                       query_stride, k_in, k_out, idx_offset, out_idx, out_score, flag);
     return hipGetLastError();
 }
 

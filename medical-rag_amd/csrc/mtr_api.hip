@@ -463,45 +463,92 @@ int enqueue_search(mtr_index* ix, S& sc, const void* dev_queries, int q_dtype, i
         if (mtr::plan_mfma(ix->dtype, ix->n, ix->ld, b, k, ix->num_cus, 0, &mplan) == 0)
             return enqueue_mfma(ix, sc, mplan, dev_queries, q_dtype, b, k, metric, nf, dev_out_idx, dev_out_score, stream);
     }
-    mtr::ScanPlan plan;
+    mtr::ScanPlan plan;   // with candidate lists of k entries
     if (mtr::plan_scan(ix->dtype, ix->n, ix->d, ix->ld, b, k, ix->num_cus, &plan) != 0)
         return fail(MTR_ERR_INVALID, "unsupported search shape (d=%d, k=%d)", ix->d, k);
+    // Long result lists: the rows are dealt evenly to the workgroups, so a workgroup's
+    // share of a query's k best rows is about k / grid, and keeping k candidates per
+    // workgroup (every wave inserting into a list of k) is what makes the scan slow for
+    // large k (10M x 1024 bf16: k = 1024 20 ms against 2.85 ms at k = 10).  The scan
+    // keeps lists of list_k < k instead (eight times the even share, at least 16), a
+    // check kernel proves afterwards that no list dropped a row of the result, and only
+    // if it cannot (rows of one neighbourhood that all match: the flag) the search runs
+    // again with full lists, enqueued behind it and a no-op otherwise.
+    mtr::ScanPlan splan = plan;
+    int list_k = k;
+    {
+        const int forced = mtr::tuning().scan_short_lists;
+        if (forced != 0 && k > 16) {
+            int c = forced;
+            if (forced < 0) {
+                const int share = 8 * ((k + plan.grid - 1) / plan.grid);
+                c = 16;
+                while (c < share) c *= 2;
+            }
+            mtr::ScanPlan t;
+            if (c >= 1 && c < k && mtr::plan_scan(ix->dtype, ix->n, ix->d, ix->ld, b, c, ix->num_cus, &t) == 0 &&
+                (forced > 0 || ix->n / t.grid >= 16ll * c)) {
+                splan = t;
+                list_k = c;
+            }
+        }
+    }
+    const bool short_lists = list_k < k;
     int rc;
-    if ((rc = sc.need(kQF32, (size_t)plan.qb * plan.qstride * 4)) != MTR_OK) return rc;
-    if ((rc = sc.need(kCandS, (size_t)plan.qb * plan.grid * k * 4)) != MTR_OK) return rc;
-    if ((rc = sc.need(kCandI, (size_t)plan.qb * plan.grid * k * 4)) != MTR_OK) return rc;
+    const int max_qb = std::max(plan.qb, splan.qb);
+    if ((rc = sc.need(kQF32, (size_t)max_qb * plan.qstride * 4)) != MTR_OK) return rc;
+    const size_t cand_cells = std::max((size_t)splan.qb * splan.grid * list_k, (size_t)plan.qb * plan.grid * k);
+    if ((rc = sc.need(kCandS, cand_cells * 4)) != MTR_OK) return rc;
+    if ((rc = sc.need(kCandI, cand_cells * 4)) != MTR_OK) return rc;
     if ((rc = sc.ready()) != MTR_OK) return rc;
-    ix->last_kernel = plan.stream_sweeps ? "scan_stream_kernel" : "scan_topk_kernel";
+    ix->last_kernel = splan.stream_sweeps ? "scan_stream_kernel" : "scan_topk_kernel";
     float* q_f32 = static_cast<float*>(sc.p[kQF32]);
     float* cand_s = static_cast<float*>(sc.p[kCandS]);
     int* cand_i = static_cast<int*>(sc.p[kCandI]);
+    int* redo = reinterpret_cast<int*>(ix->flag) + 3;   // raised by the check kernel: the lists were too short
     const int qsize = dtype_size(q_dtype);
     const bool profiling = ix->profiling && sc.may_profile();
-    for (int b0 = 0; b0 < b; b0 += plan.qb) {
-        const int nb = std::min(plan.qb, b - b0);
+    const int normalize = metric == MTR_COSINE ? 1 : 0;
+    for (int b0 = 0; b0 < b; b0 += splan.qb) {
+        const int nb = std::min(splan.qb, b - b0);
         // fp32 queries are normalised and padded inside the scan kernel; other
         // types go through the loader first (it writes all qstride columns of
         // each query it converts; unused slots of a short pass are zeroed).
         const char* qsrc = static_cast<const char*>(dev_queries) + (size_t)b0 * ix->d * qsize;
         const bool raw = q_dtype == MTR_F32;
         if (!raw) {
-            if (nb < plan.qb) HIP_TRY(mtr::launch_fill_u32(q_f32, 0u, (size_t)plan.qb * plan.qstride, stream));
-            HIP_TRY(mtr::launch_load_rows(qsrc, q_dtype, nb, ix->d, q_f32, MTR_F32, plan.qstride,
-                                          metric == MTR_COSINE ? 1 : 0, nf, stream));
+            if (nb < splan.qb) HIP_TRY(mtr::launch_fill_u32(q_f32, 0u, (size_t)splan.qb * splan.qstride, stream));
+            HIP_TRY(mtr::launch_load_rows(qsrc, q_dtype, nb, ix->d, q_f32, MTR_F32, splan.qstride, normalize, nf, stream));
         }
+        if (short_lists) HIP_TRY(mtr::launch_fill_u32(redo, 0u, 1, stream));
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (profiling) {
             if ((rc = next_event_pair(ix, &e0, &e1)) != MTR_OK) return rc;
             HIP_TRY(hipEventRecord(e0, stream));
         }
         HIP_TRY(mtr::launch_scan_topk(ix->rows, ix->dtype, ix->n, ix->ld, ix->d, q_f32,
-                                      raw ? reinterpret_cast<const float*>(qsrc) : nullptr, nb,
-                                      metric == MTR_COSINE ? 1 : 0, nf, k, plan, cand_s, cand_i, scan_sync(ix), stream));
+                                      raw ? reinterpret_cast<const float*>(qsrc) : nullptr, nb, normalize, nf, list_k, splan,
+                                      cand_s, cand_i, scan_sync(ix), stream));
         if (profiling) HIP_TRY(hipEventRecord(e1, stream));
         // the scan's per-workgroup lists are sorted best first
-        HIP_TRY(mtr::launch_merge_sorted_lists(cand_s, cand_i, plan.grid, (long long)k, (long long)plan.grid * k, k, nb, k,
-                                               ix->row_offset, dev_out_idx + (size_t)b0 * k, dev_out_score + (size_t)b0 * k,
-                                               stream));
+        long long* out_i = dev_out_idx + (size_t)b0 * k;
+        float* out_s = dev_out_score + (size_t)b0 * k;
+        HIP_TRY(mtr::launch_merge_sorted_lists(cand_s, cand_i, splan.grid, (long long)list_k, (long long)splan.grid * list_k,
+                                               list_k, nb, k, ix->row_offset, out_i, out_s, stream));
+        if (!short_lists) continue;
+        HIP_TRY(mtr::launch_check_short_lists(cand_s, cand_i, splan.grid, (long long)list_k, (long long)splan.grid * list_k,
+                                              list_k, nb, k, ix->row_offset, out_i, out_s, redo, stream));
+        // The same queries with full lists, in passes of the full plan's width (it divides
+        // this pass's: both are powers of two and longer lists never allow more queries).
+        for (int s0 = 0; s0 < nb; s0 += plan.qb) {
+            const int nbb = std::min(plan.qb, nb - s0);
+            HIP_TRY(mtr::launch_scan_topk(ix->rows, ix->dtype, ix->n, ix->ld, ix->d, q_f32 + (size_t)s0 * plan.qstride,
+                                          raw ? reinterpret_cast<const float*>(qsrc) + (size_t)s0 * ix->d : nullptr, nbb,
+                                          normalize, nf, k, plan, cand_s, cand_i, scan_sync(ix), stream, redo));
+            HIP_TRY(mtr::launch_merge_topk(cand_s, cand_i, nullptr, plan.grid, (long long)k, (long long)k,
+                                           (long long)plan.grid * k, k, nbb, k, ix->row_offset, out_i + (size_t)s0 * k,
+                                           out_s + (size_t)s0 * k, stream, redo));
+        }
     }
     return MTR_OK;
 }
@@ -957,6 +1004,7 @@ const TuningField kTuningFields[] = {
     {"mfma_sample_stride", &mtr::Tuning::mfma_sample_stride}, {"mfma_stream_rows", &mtr::Tuning::mfma_stream_rows},
     {"mfma_interleave", &mtr::Tuning::mfma_interleave},   {"mfma_stages", &mtr::Tuning::mfma_stages},           {"mfma_tile_rows", &mtr::Tuning::mfma_tile_rows},
     {"wide_min_batch", &mtr::Tuning::wide_min_batch},     {"wide_qgroup", &mtr::Tuning::wide_qgroup},
+    {"scan_short_lists", &mtr::Tuning::scan_short_lists},
     {"scan_wg_per_cu", &mtr::Tuning::scan_wg_per_cu},     {"scan_form", &mtr::Tuning::scan_form},
     {"scan_static_permille", &mtr::Tuning::scan_static_permille}, {"scan_pair_permille", &mtr::Tuning::scan_pair_permille},
     {"scan_chunk_groups", &mtr::Tuning::scan_chunk_groups}, {"scan_late_refill", &mtr::Tuning::scan_late_refill},

@@ -61,6 +61,7 @@ struct Tuning {
     int scan_wg_per_cu = 0;       // scan workgroups per CU (0: one for a single query, occupancy otherwise)
     int scan_max_qb = 0;          // most queries per scan pass 1 / 2 / 4 / 8 (0: four)
     int scan_nontemporal = -1;    // -1: streaming row loads on shards beyond the caches; 0 / 1
+    int scan_short_lists = -1;    // scan candidate lists shorter than k, verified afterwards: -1 by shape; 0 never; n: lists of n (k > n)
     int scan_form = 0;            // single-query scan: 0 by shard size; 1 classic form; 2 streaming form wherever the shape allows
     int scan_static_permille = 0; // streaming form: share of the row groups the waves take by index (0: 880) ...
     int scan_chunk_groups = 0;    // ... groups per claimed chunk of a first phase (0: one) ...
@@ -120,6 +121,7 @@ int plan_scan(int dtype, int64_t n, int d, int ld, int b, int k, int num_cus, Sc
 // Row scan + fused per-workgroup top-k.  q: plan.qb padded fp32 queries
 // ([qb][qstride]); outputs [qb][grid][k] candidate (score, local row) lists,
 // each sorted, padded with (-inf, -1).
+// run_if != NULL: the kernel does nothing while that device word is 0.
 // sync: 32 device words, zero between launches, that the streaming form's waves claim rows
 // through (a shard's launches must not overlap on them); unused by the classic form.
 // Instead of prepared queries (q), the first nb raw fp32 queries ([nb][d],
@@ -127,7 +129,8 @@ int plan_scan(int dtype, int64_t n, int d, int ld, int b, int k, int num_cus, Sc
 // pads them itself and reports NaN/inf through nonfinite_flag.
 hipError_t launch_scan_topk(const void* rows, int dtype, int64_t n, int ld, int d, const float* q,
                             const float* q_raw, int nb, int normalize, NonfiniteFlag nonfinite_flag, int k,
-                            const ScanPlan& plan, float* cand_s, int* cand_i, unsigned int* sync, hipStream_t stream);
+                            const ScanPlan& plan, float* cand_s, int* cand_i, unsigned int* sync, hipStream_t stream,
+                            const int* run_if = nullptr);
 
 // Candidate merge: for each of b queries, the best k_out of n_lists * k_in
 // candidates.  Candidate (list l, query q, slot j) sits at
@@ -234,6 +237,13 @@ hipError_t launch_score_wide(const void* rows, int64_t n, int ld, const void* qu
 
 // floors[0..words) = 0 when *flag != 0 (device word); nothing otherwise.
 hipError_t launch_reset_floors_if(unsigned int* floors, int words, const int* flag, hipStream_t stream);
+
+// Raises *flag (a device word) when lists of k_in < k_out candidates per query were too
+// short for the merged result out_idx / out_score to be certain: some full list's last
+// entry beats the merged k_out-th entry.  Lists sorted best first, padded with id -1.
+hipError_t launch_check_short_lists(const float* cand_s, const int* cand_i, int n_lists, long long list_stride,
+                                    long long query_stride, int k_in, int b, int k_out, long long idx_offset,
+                                    const long long* out_idx, const float* out_score, int* flag, hipStream_t stream);
 
 // The same for lists that are each sorted best first (score descending, row
 // ascending; short lists padded with id -1 at the end), 32-bit ids: by the

@@ -89,12 +89,14 @@ struct ScanArgs {
     int k;
     float* cand_s; // [QB][gridDim.x][k]
     int* cand_i;
+    const int* run_if;   // not NULL: the kernel does nothing while this device word is 0
 };
 
 template <typename T, int QB, bool NT>
 __global__ __launch_bounds__(waves_per_group(QB) * 64) void scan_topk_kernel(ScanArgs a) {
     constexpr int kWaves = waves_per_group(QB);
     constexpr int EPC = Chunk<T>::EPC;
+    if (a.run_if && *a.run_if == 0) return;
     static_assert(kQuads * QB <= kLanesPerRow, "one lane of a row's sixteen per (quad, query) total");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -537,6 +539,7 @@ __device__ __forceinline__ void stage_raw_query(const ScanArgs& a, const float* 
 // top-k (the ceiling measurement of this form).
 template <typename T, bool NT, int SWEEPS, bool ARITH>
 __global__ __launch_bounds__(kStreamThreads) void scan_stream_kernel(ScanArgs a, StreamSplit sp) {
+    if (a.run_if && *a.run_if == 0) return;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* q_lds = reinterpret_cast<float*>(smem);
     float* list_s = q_lds + a.qstride;
@@ -959,7 +962,8 @@ hipError_t launch_scan_read_only(const void* rows, int dtype, int64_t n, int ld,
 
 hipError_t launch_scan_topk(const void* rows, int dtype, int64_t n, int ld, int d, const float* q,
                             const float* q_raw, int nb, int normalize, NonfiniteFlag nonfinite_flag, int k,
-                            const ScanPlan& plan, float* cand_s, int* cand_i, unsigned int* sync, hipStream_t stream) {
+                            const ScanPlan& plan, float* cand_s, int* cand_i, unsigned int* sync, hipStream_t stream,
+                            const int* run_if) {
     const int esize = dtype == 0 ? 4 : 2;
     ScanArgs a;
     a.rows = static_cast<const char*>(rows);
@@ -977,6 +981,7 @@ hipError_t launch_scan_topk(const void* rows, int dtype, int64_t n, int ld, int 
     a.k = k;
     a.cand_s = cand_s;
     a.cand_i = cand_i;
+    a.run_if = run_if;
     if (plan.stream_sweeps) {
         if (!sync || plan.qb != 1) return hipErrorInvalidValue;
         const StreamSplit sp = stream_split(n, plan.grid, sync);
