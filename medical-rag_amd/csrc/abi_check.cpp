@@ -119,6 +119,10 @@ int main() {
     EXPECT(mtr_index_nonfinite(nullptr, nullptr) == MTR_ERR_INVALID);
     EXPECT(mtr_index_profile(nullptr, 1) == MTR_ERR_INVALID);
     EXPECT(mtr_index_read_ceiling(nullptr, 1, nullptr) == MTR_ERR_INVALID);
+    {
+        char name[8];
+        EXPECT(mtr_index_last_kernel(nullptr, name, 8) == MTR_ERR_INVALID);
+    }
     EXPECT(mtr_merge_topk_device(nullptr, nullptr, 1, 0, 0, 1, 1, 1, nullptr, nullptr, 0, nullptr) == MTR_ERR_INVALID);
     EXPECT(mtr_pool_normalize(nullptr, 0, nullptr, 1, 1, 1, nullptr, 0, nullptr) == MTR_ERR_INVALID);
     EXPECT(mtr_comm_create(nullptr, 0, 1, 0, nullptr) == MTR_ERR_INVALID);

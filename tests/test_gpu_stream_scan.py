@@ -99,11 +99,18 @@ def test_streaming_form_read_ceiling_runs(native):
     q = torch.randn((1, d), generator=gen, device="cuda")
     shard = native.DeviceShard.alloc(n, d, store_dtype="bf16")
     shard.load_device(0, rows)
+    assert shard.last_kernel() == ""
     with native.options(scan_form=2):
         want = tuple(t.clone() for t in shard.search_device(q, k=10))
+        assert shard.last_kernel() == "scan_stream_kernel"
         ms = shard.read_ceiling(reps=3)
         assert ms > 0
         got = shard.search_device(q, k=10)
         torch.cuda.synchronize()
         assert torch.equal(want[0], got[0]) and torch.equal(want[1], got[1])
+    with native.options(scan_form=1):
+        shard.search_device(q, k=10)
+        assert shard.last_kernel() == "scan_topk_kernel"
+    shard.search_device(torch.randn((40, d), generator=gen, device="cuda"), k=10)
+    assert shard.last_kernel() == "score_topk_mfma_kernel"
     shard.close()
