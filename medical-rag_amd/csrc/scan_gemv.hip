@@ -366,7 +366,7 @@ __global__ __launch_bounds__(waves_per_group(1) * 64) void scan_read_only_kernel
 // finish at 2.6 ms), so an even split ends when the slowest CU does.  Here a
 // wave takes a fixed share of the groups first (most of them: wave w of W takes
 // groups w, w + W, ...), and the rest is handed out through a device-wide
-// counter in chunks of two groups and finally of one.  The claims are few (the
+// counter, group by group.  The claims are few (the
 // counter takes about one claim per 5 ns) and are made by a fifth wave of the
 // workgroup, which does nothing else: an atomic with return sits in its wave's
 // queue of loads, which return in order, so in a scanning wave a slow claim
