@@ -426,7 +426,8 @@ int enqueue_mfma(mtr_index* ix, S& sc, const mtr::MfmaPlan& plan, const void* de
         HIP_TRY(mtr::launch_reset_floors_if(floors, floor_words, overflow, stream));
     }
     ix->last_kernel = use_wide ? "score_filter_wide_kernel" : "score_topk_mfma_kernel";
-    const mtr::MfmaPass all{1, nullptr, overflow, floor_words};
+    mtr::MfmaPass all{1, nullptr, overflow, floor_words};
+    all.sync = scan_sync(ix);
     HIP_TRY(mtr::launch_score_mfma(ix->rows, ix->dtype, ix->n, ix->ld, qbuf, b, k, plan, all, sc.p[kMfmaCand],
                                    floors, lists_s, lists_i, stream));
     if (profiling && !use_wide) HIP_TRY(hipEventRecord(e1, stream));
@@ -1002,7 +1003,8 @@ const TuningField kTuningFields[] = {
     {"mfma_min_batch", &mtr::Tuning::mfma_min_batch},     {"mfma_tnq", &mtr::Tuning::mfma_tnq},
     {"mfma_per_cu", &mtr::Tuning::mfma_per_cu},           {"mfma_cap", &mtr::Tuning::mfma_cap},
     {"mfma_sample_stride", &mtr::Tuning::mfma_sample_stride}, {"mfma_stream_rows", &mtr::Tuning::mfma_stream_rows},
-    {"mfma_interleave", &mtr::Tuning::mfma_interleave},   {"mfma_stages", &mtr::Tuning::mfma_stages},           {"mfma_tile_rows", &mtr::Tuning::mfma_tile_rows},
+    {"mfma_interleave", &mtr::Tuning::mfma_interleave},   {"mfma_dynamic_tail", &mtr::Tuning::mfma_dynamic_tail},
+    {"mfma_static_permille", &mtr::Tuning::mfma_static_permille},   {"mfma_stages", &mtr::Tuning::mfma_stages},           {"mfma_tile_rows", &mtr::Tuning::mfma_tile_rows},
     {"wide_min_batch", &mtr::Tuning::wide_min_batch},     {"wide_qgroup", &mtr::Tuning::wide_qgroup},
     {"scan_short_lists", &mtr::Tuning::scan_short_lists},
     {"scan_wg_per_cu", &mtr::Tuning::scan_wg_per_cu},     {"scan_form", &mtr::Tuning::scan_form},

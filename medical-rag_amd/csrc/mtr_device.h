@@ -55,6 +55,8 @@ struct Tuning {
     int mfma_stream_rows = -1;    // -1: streaming row loads when one query tile reads a shard beyond the caches; 0 / 1
     int mfma_stages = 0;          // LDS stage buffers 2 / 3 (0: by form)
     int mfma_tile_rows = 0;       // rows per tile 128 / 256 (0: by form)
+    int mfma_dynamic_tail = -1;   // -1: the tall ring forms claim their last tiles from a counter; 0 / 1
+    int mfma_static_permille = 0; // ... share of the tiles taken by index in that form (0: 930)
     int mfma_interleave = -1;     // -1: ranges interleaved tile by tile when one query tile streams a large shard; 0 / 1
     int wide_min_batch = 129;     // smallest batch for the 256 x 256-tile kernel
     int wide_qgroup = 0;          // its query tiles per row list on one XCD (0: four)
@@ -168,6 +170,8 @@ struct MfmaPlan {
     int stream_rows;          // row tiles loaded with the streaming (nt) cache policy
     int stages;               // LDS stage buffers: 2, or 3 (ring with counted waits)
     int interleave;           // row ranges interleaved tile by tile instead of contiguous stretches
+    int dynamic_tail;         // ... and the last tiles claimed from a device-wide counter (needs MfmaPass::sync)
+    long long static_tiles;   // tiles every range takes by index in that form
 };
 
 // Launch shape of the matrix-core scoring kernel; -1 when the shape is not
@@ -186,6 +190,7 @@ struct MfmaPass {
     unsigned int* tile_max;   // [n_qtiles*tnq][plan.n_tiles] order-preserving score bits, or NULL
     const int* run_if;        // not NULL: the launch does nothing while this device word is 0
     int padded_queries;       // queries the caller's query, floor and tile_max buffers hold (the launch needs n_qtiles * tnq)
+    unsigned int* sync = nullptr;   // 32 device words, zero between launches, for the form that claims its last tiles (NULL: never that form)
 };
 
 // rows x queries on the matrix cores with fused top-k, both in the shard's storage type

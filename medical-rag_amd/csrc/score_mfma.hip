@@ -96,6 +96,8 @@ struct MfmaArgs {
     int* out_i;
     const int* run_if;       // not NULL: do nothing while *run_if == 0
     int interleave;          // 1: range r takes tiles r, r + n_ranges, ... instead of a contiguous stretch (tile_stride 1 only)
+    long long static_tiles;  // DYN forms: tiles every range takes by index (range r: r, r + n_ranges, ...); the rest is claimed
+    unsigned int* sync;      // DYN forms: [0] claim counter, [16] workgroups whose claimer has finished; zero between launches
 };
 
 template <int AUX, int ROWS, int WAVES>
@@ -441,8 +443,17 @@ __device__ __forceinline__ void write_range_lists(int q0, int nq, int qt_base, i
 // TM: rows per tile.  256 (64-query tiles in the ring form only): eight waves,
 // each 32 rows x 64 queries, one workgroup per CU; the query tile's re-staging
 // then adds a quarter to the row bytes that go into LDS instead of a half.
-template <typename T, int CAP, int TNQ, bool MAX_ONLY, int ROW_AUX, int NS, int TM = kTileRows>
-__global__ __launch_bounds__(TM == 256 ? 512 : 256, TM == 256 ? 1 : 2) void score_topk_mfma_kernel(MfmaArgs a) {
+// DYN (ring form, one query tile, 256-row tiles): the ranges take most of the tiles
+// by index, side by side (range r: tiles r, r + R, ...), and the last ones are
+// claimed tile by tile from a device-wide counter, so that CUs the memory system
+// serves faster end up with more rows (with an even split the median workgroup
+// is done 40-130 us before the last one of a 2.9 ms launch).  A ninth wave makes
+// the claims -- an atomic issued by a loading wave would sit in front of its
+// counted waits -- and hands the tile numbers on through LDS; it takes part in
+// every barrier of the eight others and does nothing else.
+template <typename T, int CAP, int TNQ, bool MAX_ONLY, int ROW_AUX, int NS, int TM = kTileRows, bool DYN = false>
+__global__ __launch_bounds__(DYN ? 576 : TM == 256 ? 512 : 256, TM == 256 ? 1 : 2) void score_topk_mfma_kernel(MfmaArgs a) {
+    static_assert(!DYN || (NS == 3 && TM == 256 && !MAX_ONLY), "claimed tiles exist in the tall ring form only");
     static_assert(NS == 2 || (NS == 3 && !MAX_ONLY), "the ring form exists for the full launch only");
     static_assert(TM == 128 || (TM == 256 && NS == 3), "the tall tile exists in the ring form only");
     static_assert(NS == 2 || TNQ % (8 * (TM == 256 ? 8 : 4)) == 0 || TNQ / 8 < (TM == 256 ? 8 : 4),
@@ -528,6 +539,121 @@ __global__ __launch_bounds__(TM == 256 ? 512 : 256, TM == 256 ? 1 : 2) void scor
         for (int n = 0; n < NQ16; ++n) acc16[m][n] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
     const long long total_steps = my_tiles * ksteps;
+    if constexpr (DYN) {
+        constexpr int LPS_ROWS = TM / (8 * WAVES);
+        constexpr bool kUnevenQ = TNQ < 8 * WAVES;
+        constexpr int LPS = LPS_ROWS + (kUnevenQ ? 0 : TNQ / (8 * WAVES));
+        // The workgroup's j-th tile: by index while j < S, else what the claimer put into
+        // seq[j & 3] (-1: no such tile, nor any later one).  The waves use entries j and
+        // j + 1 (the requests run two K steps ahead), the claimer writes entry j + 2.
+        int* seq = reinterpret_cast<int*>(smem + NS * kStageBytes + TN * 12 + WAVES * 1024);
+        const long long R = a.n_ranges, S = a.static_tiles;
+        const long long dyn_first = S * R;
+        if (wave == WAVES) {
+            // ---- the claimer ----
+            long long m0 = -1, m1 = -1, m2 = -1, m3 = -1;   // its copy of seq (scalars: an indexed array would live in scratch)
+            bool ended = false;                              // a claim has come back past the end
+            unsigned int opaque_zero;
+            asm volatile("v_mov_b32 %0, 0" : "=v"(opaque_zero));
+            for (long long j = 0;; ++j) {
+                const int e = (int)(j & 3);
+                const long long pj = j < S ? j * R + range : (e == 0 ? m0 : e == 1 ? m1 : e == 2 ? m2 : m3);
+                if (pj < 0) break;
+                const bool wanted = j + 2 >= S;
+                const bool claims = wanted && !ended;
+                // The claim is issued here and read behind the tile's K steps.  (Only lane 0's value
+                // is read; the other lanes' stays undefined, and the address is one the compiler cannot
+                // prove uniform: either would otherwise make it wait for the result on the spot.)
+                unsigned int tick;
+                if (claims && lane == 0)
+                    tick = __hip_atomic_fetch_add(a.sync + opaque_zero, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int ks = 0; ks < ksteps; ++ks) barrier_keeping_loads();   // the K steps' barriers
+                if (wanted) {
+                    long long p = -1;
+                    if (claims) {
+                        p = dyn_first + (long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)tick);
+                        if (p >= n_tiles) { p = -1; ended = true; }
+                    }
+                    const int w = (int)((j + 2) & 3);
+                    if (w == 0) m0 = p; else if (w == 1) m1 = p; else if (w == 2) m2 = p; else m3 = p;
+                    if (lane == 0) seq[w] = (int)p;
+                }
+                barrier_keeping_loads();   // the barrier at the tile's end: entry j + 2 is visible from here on
+            }
+            __syncthreads();               // ... and the one in front of the final selection
+            if (lane == 0) {
+                const unsigned int before = __hip_atomic_fetch_add(a.sync + 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (before + 1u == gridDim.x) {   // the launch's last claimer leaves the counters at zero
+                    __hip_atomic_store(a.sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(a.sync + 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            return;
+        }
+        auto tile_of = [&](long long j) -> long long {
+            if (j < S) return j * R + range;
+            return (long long)__builtin_amdgcn_readfirstlane(seq[j & 3]);
+        };
+        const bool extra_q = kUnevenQ && wave < TNQ / 8;
+        // request cursor: K step ld_ks of the workgroup's ld_j-th tile (ld_ptile, -1: past the last tile)
+        long long ld_j = 0, ld_ptile = S > 0 ? (long long)range : -1, queued = -1;
+        int ld_ks = 0, ld_stage = 0;
+        auto request_step = [&]() {
+            char* st = stage0 + ld_stage * kStageBytes;
+            stage_tile<ROW_AUX, TM, WAVES>(a.rows, ld_ptile * TM, a.n - 1, row_bytes, ld_ks * kStepBytes, st, wave, lane);
+            stage_tile<0, TNQ, WAVES>(qbase, 0, TN - 1, row_bytes, ld_ks * kStepBytes, st + TM * kStepBytes, wave, lane);
+            ld_stage = ld_stage == NS - 1 ? 0 : ld_stage + 1;
+            if (++ld_ks == ksteps) {
+                ld_ks = 0;
+                ++ld_j;
+                ld_ptile = tile_of(ld_j);
+                queued = ld_ptile;   // what the compute cursor moves on to at its tile's end
+            }
+        };
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // (the launcher only picks this form for S >= 2 and at least four K steps per tile)
+        request_step();
+        request_step();
+        long long ptile = (long long)range;
+        int ks = 0, cur = 0;
+        while (ptile >= 0) {
+            // step (ptile, ks) has landed when all but the next step's loads have (this wave's share; the barrier extends it to all)
+            const bool has_next = ks + 1 < ksteps || queued >= 0;
+            if (!has_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (extra_q) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS + 1) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+            barrier_keeping_loads();
+            // every wave is past the MFMAs of the previous step: its buffer takes the step after next
+            if (ld_ptile >= 0) request_step();
+            if (ks == 0 && tid < TN)
+                pending_floor = __hip_atomic_load(shared_floor + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const char* st = stage0 + cur * kStageBytes;
+            mfma_step<MT, NT>(T{}, st, st + TM * kStepBytes, row_off, q_off, lane, acc);
+            cur = cur == NS - 1 ? 0 : cur + 1;
+            if (ks + 1 == ksteps) {
+                const long long row_base = ptile * TM + row_off + 4 * (lane >> 5);
+                const bool last_tile = (ptile + 1) * TM > a.n;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const int ql = q_off + n * 32 + (lane & 31);
+                    const float thr = fmaxf(floor_lds[ql], unorder_f32(order_f32(shared_lds[ql]) - 1u));
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+                        append_above<CAP, true>(acc[m][n], thr, ql, row_base + m * 32, last_tile, a, cnt_lds, my_buf);
+                }
+                barrier_keeping_loads();  // counts and keys of this tile are visible to the selecting waves
+                if (tid < TN) shared_lds[tid] = unorder_f32(pending_floor | (pending_floor == 0 ? 0x007fffffu : 0u));
+                reselect_where_full<CAP>(wave * QPW, QPW, TM, lane, a, floor_lds, cnt_lds, my_buf, shared_floor, hist_lds);
+                ks = 0;
+                ptile = queued;
+            } else {
+                ++ks;
+            }
+        }
+        __syncthreads();
+        write_range_lists<CAP>(wave * QPW, QPW, qt * TN, range, lane, a, floor_lds, cnt_lds, my_buf, shared_floor, hist_lds);
+        return;
+    }
     if constexpr (NS == 3) {
         // Load instructions per wave and step: the row pieces, plus the wave's query pieces
         // (one for the first TNQ / 8 waves only when the query tile has fewer pieces than waves).
@@ -791,6 +917,25 @@ int plan_mfma(int dtype, int64_t n, int ld, int b, int k, int num_cus, int sampl
     plan->interleave = (plan->stream_rows && plan->n_qtiles == 1) ? 1 : 0;
     if (tn.mfma_interleave >= 0) plan->interleave = !sampling && tn.mfma_interleave != 0;
     plan->lds = lds_bytes(tm, plan->tnq, plan->stages);
+    // ... and take the last tiles from a counter (tall ring forms of up to 64 queries, rows of at
+    // least four K steps, many tiles per range).  Measured on 10M x 1024 and 12.5M x 768 bf16: 0.5 to
+    // 1.5 % off the launch, except the 64-query tile over rows of 2 KB and more, which loses 0.2 %.
+    plan->dynamic_tail = 0;
+    plan->static_tiles = 0;
+    {
+        const long long per_range = plan->n_tiles / plan->n_ranges;
+        const bool can = plan->interleave && tm == 256 && plan->stages == 3 && plan->tnq <= 64 && ld * esize >= 4 * kStepBytes &&
+                         per_range >= 4;
+        const bool gains = plan->tnq <= 32 || (long long)ld * esize < 2048;
+        const bool want = tn.mfma_dynamic_tail >= 0 ? tn.mfma_dynamic_tail != 0 : per_range >= 16 && gains;
+        if (can && want) {
+            plan->dynamic_tail = 1;
+            const int permille = tn.mfma_static_permille > 0 ? tn.mfma_static_permille : 930;
+            plan->static_tiles = (long long)((double)plan->n_tiles * permille * 1e-3) / plan->n_ranges;
+            if (plan->static_tiles < 2) plan->static_tiles = 2;
+            plan->lds += 16;   // the claimer's four-entry tile ring
+        }
+    }
     plan->cand_bytes = (size_t)plan->grid * plan->tnq * plan->cap * 8;
     return 0;
 }
@@ -836,11 +981,14 @@ hipError_t launch_score_mfma(const void* rows, int dtype, int64_t n, int ld, con
     a.out_i = out_i;
     a.run_if = pass.run_if;
     a.interleave = plan.interleave && a.tile_stride == 1 && a.tile_max == nullptr;
+    const bool dyn = plan.dynamic_tail && a.interleave && pass.sync != nullptr && plan.tm == 256 && plan.stages == 3 && plan.tnq <= 64;
+    a.static_tiles = dyn ? plan.static_tiles : 0;
+    a.sync = pass.sync;
     auto launch = [&](auto kernel) -> hipError_t {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kernel, dim3(plan.grid), dim3(plan.tm == 256 ? 512 : kThreads), plan.lds, stream, a);
+        hipLaunchKernelGGL(kernel, dim3(plan.grid), dim3(dyn ? 576 : plan.tm == 256 ? 512 : kThreads), plan.lds, stream, a);
         return hipGetLastError();
     };
 #define MTR_MFMA_PICK(T, AUX)                                                                         \
@@ -883,6 +1031,8 @@ hipError_t launch_score_mfma(const void* rows, int dtype, int64_t n, int ld, con
 #undef MTR_MFMA_PICK16
     if (plan.tm == 256) {
         if (plan.stages != 3 || plan.cap != 512 || dtype != 2 || a.tile_max != nullptr) return hipErrorInvalidValue;
+        if (dyn && plan.tnq == 32) return launch(&score_topk_mfma_kernel<bf16_t, 512, 32, false, 2, 3, 256, true>);
+        if (dyn && plan.tnq == 64) return launch(&score_topk_mfma_kernel<bf16_t, 512, 64, false, 2, 3, 256, true>);
         if (plan.tnq == 32) return launch(&score_topk_mfma_kernel<bf16_t, 512, 32, false, 2, 3, 256>);
         if (plan.tnq == 64) return launch(&score_topk_mfma_kernel<bf16_t, 512, 64, false, 2, 3, 256>);
         if (plan.tnq == 128) return launch(&score_topk_mfma_kernel<bf16_t, 512, 128, false, 2, 3, 256>);

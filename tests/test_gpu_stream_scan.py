@@ -114,3 +114,41 @@ def test_streaming_form_read_ceiling_runs(native):
     shard.search_device(torch.randn((40, d), generator=gen, device="cuda"), k=10)
     assert shard.last_kernel() == "score_topk_mfma_kernel"
     shard.close()
+
+
+@pytest.mark.parametrize("n,d,b", [(300_011, 256, 64), (400_000, 320, 33), (290_000, 512, 2), (1_200_000, 256, 20)])
+def test_matrix_core_ring_with_claimed_tail(native, n, d, b):
+    """The tall ring form of the matrix-core kernel with its ranges interleaved and
+    the last tiles claimed from a counter (a ninth wave claims), forced onto shards
+    of a few tiles per workgroup: integer rows, so ids and scores equal the oracle
+    bit for bit; the answer of the form with an even split is the same bits on
+    real-valued rows; searched three times in a row (the counters go back to zero)."""
+    import torch
+    rng = np.random.default_rng(n + d + b)
+    forms = dict(mfma_stream_rows=1, mfma_stages=3, mfma_tile_rows=256, mfma_sample_stride=0)
+    if n <= 400_000:
+        corpus = rng.integers(-3, 4, size=(n, d)).astype(np.float32)
+        queries = rng.integers(-3, 4, size=(b, d)).astype(np.float32)
+        corpus[n - 1] = queries[0]
+        shard = native.DeviceShard.from_host(corpus, store_dtype="bf16", normalize=False)
+        want_i, want_s = orc.search(queries, corpus, 10, metric="ip")
+        for permille in (880, 500, 990):
+            with native.options(mfma_dynamic_tail=1, mfma_static_permille=permille, **forms):
+                for _ in range(3):
+                    idx, score = shard.search(queries, k=10, metric="ip")
+                    assert (idx == want_i).all(), (n, d, b, permille)
+                    assert (score == want_s.astype(np.float32)).all(), (n, d, b, permille)
+        shard.close()
+    gen = torch.Generator(device="cuda").manual_seed(n)
+    rows = torch.randn((n, d), generator=gen, device="cuda")
+    q = torch.randn((b, d), generator=gen, device="cuda")
+    shard = native.DeviceShard.alloc(n, d, store_dtype="bf16")
+    shard.load_device(0, rows)
+    with native.options(mfma_dynamic_tail=0, **forms):
+        ei, es = (t.clone() for t in shard.search_device(q, k=10))
+    with native.options(mfma_dynamic_tail=1, **forms):
+        for _ in range(3):
+            di, ds = (t.clone() for t in shard.search_device(q, k=10))
+            torch.cuda.synchronize()
+            assert torch.equal(ei, di) and torch.equal(es, ds)
+    shard.close()
