@@ -275,13 +275,20 @@ int mfma_min_batch(int dtype) {
 // Every how many row tiles one goes into the sampling launch (< 2: no sample).
 // The sample costs 1/stride of a full launch; what the full launch appends
 // shrinks as k * n / sample.  A sample of about 5 * sqrt(k * n) rows balanced
-// the two on 1M and 12.5M rows at k 10 and 100.  The sample needs at least 2k
-// tiles (its floor is the k-th largest per-tile best score) and at most
-// kMaxSampleTiles.
+// the two for the wide kernel (whose sample is matrix-core work like its full
+// launch) on 1M and 12.5M rows at k 10 and 100.  The general kernel's appends
+// cost its workgroups time in proportion to the queries of a tile, while its
+// sample only reads rows: with `b` > 0 (the queries of one tile) the sample grows
+// with sqrt(b), up to 2.5 times (12.5M x 768 bf16, k 10, whole search at strides
+// 223 / 128 / 90 / 45: 64 queries 2.828 / 2.822 / 2.817 / 2.840 ms, 32 queries
+// 2.747 / 2.743 / 2.736 / 2.759, 8 queries 2.724 / 2.735 / 2.729 / 2.758).
+// The sample needs at least 2k tiles (its floor is the k-th largest per-tile best
+// score) and at most kMaxSampleTiles.
 constexpr double kMinTwoPassBytes = 1.0e9;
-int sample_stride(long long n, long long n_tiles, int k) {
+int sample_stride(long long n, long long n_tiles, int k, int b = 0) {
     const int forced = mtr::tuning().mfma_sample_stride;
-    long long s = forced >= 0 ? forced : (long long)(std::sqrt((double)n / (double)k) / 5.0);
+    const double div = b > 0 ? std::min(12.5, std::max(5.0, 2.2 * std::sqrt((double)b))) : 5.0;
+    long long s = forced >= 0 ? forced : (long long)(std::sqrt((double)n / (double)k) / div);
     if (forced < 0) s = std::min<long long>(1024, std::max<long long>(4, s));
     if (s < 2) return 0;
     s = std::max(s, (n_tiles + mtr::kMaxSampleTiles - 1) / mtr::kMaxSampleTiles);
@@ -342,7 +349,7 @@ int enqueue_mfma(mtr_index* ix, S& sc, const mtr::MfmaPlan& plan, const void* de
     // wide kernel starts without floors).
     // The sampling launch works on 128-row tiles whatever the full launch uses.
     const long long stiles = (ix->n + 127) / 128;
-    const int stride = (big && !use_wide) ? sample_stride(ix->n, stiles, k) : 0;
+    const int stride = (big && !use_wide) ? sample_stride(ix->n, stiles, k, std::min(b, plan.tnq)) : 0;
     mtr::MfmaPlan samp = plan;
     if (stride >= 2) {
         const long long n_samp = (stiles + stride - 1) / stride;

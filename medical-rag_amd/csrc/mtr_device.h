@@ -184,7 +184,8 @@ int plan_mfma(int dtype, int64_t n, int ld, int b, int k, int num_cus, int sampl
 // tile_stride-th tile that only records each query's best score per tile
 // (tile_max), whose k-th largest per query (launch_floor_from_tile_max) is a
 // valid starting floor for the full launch (tile_stride 1, tile_max NULL).
-constexpr int kMaxSampleTiles = 1024;
+constexpr int kMaxSampleKeys = 1024;    // keys per query the floor kernel selects among ...
+constexpr int kMaxSampleTiles = 8192;   // ... and tiles of a sampling launch (taken in groups beyond that many)
 struct MfmaPass {
     int tile_stride;
     unsigned int* tile_max;   // [n_qtiles*tnq][plan.n_tiles] order-preserving score bits, or NULL

@@ -281,52 +281,44 @@ __device__ __forceinline__ void compact_query(unsigned long long* buf, int c, in
 // One 32 x 32 MFMA tile of finished scores (one query per lane column, 16 rows
 // per lane: row0 + (r & 3) + 8 * (r >> 2) for register r): appends what is
 // above the query's threshold to its candidate buffer and clears the tile.
-// WAIT_STORES: the wave waits for its stores before it goes on (the caller's
-// next barrier then makes them visible to the workgroup without draining the
-// loads of waves that stored nothing).
-template <int CAP, bool WAIT_STORES>
+// The wave does not wait for its stores: whoever reads the keys (a re-selection,
+// the final selection) has every wave wait in front of a barrier first.
+template <int CAP>
 __device__ __forceinline__ void append_above(f32x16& tile, float thr, int ql, long long row0, bool last_tile,
                                              const MfmaArgs& a, int* cnt_lds, unsigned long long* my_buf) {
-    float mx = tile[0];
+    // registers 4 g .. 4 g + 3 hold rows row0 + 8 g .. + 3
+    float gmax[4];
 #pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, tile[r]);
+    for (int g = 0; g < 4; ++g) gmax[g] = fmaxf(fmaxf(tile[4 * g], tile[4 * g + 1]), fmaxf(tile[4 * g + 2], tile[4 * g + 3]));
+    const float mx = fmaxf(fmaxf(gmax[0], gmax[1]), fmaxf(gmax[2], gmax[3]));
     if (__any(mx > thr)) {
-        unsigned int pass = 0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) pass |= (tile[r] > thr) ? (1u << r) : 0u;
-        if (last_tile) {  // only the last tile of the matrix can hold rows past its end
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (row0 + (r & 3) + 8 * (r >> 2) >= a.n) pass &= ~(1u << r);
-        }
-        // One LDS atomic per lane reserves all its slots at once (a
-        // returning atomic per element would serialise on LDS latency).
-        int slot = 0;
-        if (pass) {
-            const int np = __popc(pass);
-            slot = atomicAdd(&cnt_lds[ql], np);
-            if (MTR_TIMING(a) & 4) atomicAdd(a.debug_counters, (unsigned long long)np);
-        }
-        // Registers any lane wants to store, as a wave-uniform mask: the
-        // sixteen tests below are then scalar branches.  (Letting every
-        // lane walk its own passing rows instead, with a select tree to
-        // fetch element r, measured 5-15 % slower at every batch size.)
-        unsigned int any_r = pass;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) any_r |= __shfl_xor(any_r, off, 64);
-        any_r = __builtin_amdgcn_readfirstlane(any_r);
+        // As a rule ONE lane holds ONE such score.  It is found behind wave-uniform tests
+        // (a compare into the condition mask and a scalar branch each: four groups, then the
+        // four registers of a group that holds one) and takes its slot with an LDS atomic of
+        // its own.  (Letting every lane walk its own passing rows instead, with a select tree
+        // to fetch element r, measured 5-15 % slower at every batch size; counting the lane's
+        // scores first, to reserve their slots at once, costs more than the atomics it saves.)
+        // Only the last tile of the matrix can hold rows past its end.
+        const long long left = a.n - row0;
+        const int rows_left = !last_tile || left > 32 ? 32 : left < 0 ? 0 : (int)left;
         unsigned long long* dst = my_buf + (size_t)ql * CAP;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            if (any_r & (1u << r)) {
-                if (pass & (1u << r)) {
-                    if (MTR_TIMING(a) & 2) slot &= CAP - 1;
-                    if (slot < CAP) dst[slot] = pack_key(tile[r], (int)(row0 + (r & 3) + 8 * (r >> 2)));
-                    ++slot;
+        for (int g = 0; g < 4; ++g) {
+            if (__any(gmax[g] > thr)) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool hit = tile[4 * g + j] > thr && 8 * g + j < rows_left;
+                    if (__any(hit)) {
+                        if (hit) {
+                            int slot = atomicAdd(&cnt_lds[ql], 1);
+                            if (MTR_TIMING(a) & 4) atomicAdd(a.debug_counters, 1ull);
+                            if (MTR_TIMING(a) & 2) slot &= CAP - 1;
+                            if (slot < CAP && !(MTR_TIMING(a) & 8)) dst[slot] = pack_key(tile[4 * g + j], (int)(row0 + 8 * g + j));
+                        }
+                    }
                 }
             }
         }
-        if constexpr (WAIT_STORES) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) tile[r] = 0.f;
@@ -395,6 +387,20 @@ __device__ __forceinline__ void reselect_where_full(int q0, int nq, int tile_row
     }
 }
 
+// True (in every wave alike) when some query's buffer could overflow on the next
+// tile.  Called between the barrier behind a tile's appends and the next barrier,
+// while nobody changes the counts.
+template <int CAP, int TN>
+__device__ __forceinline__ bool any_buffer_full(const int* cnt_lds, int tile_rows, int lane) {
+    bool full = false;
+#pragma unroll
+    for (int i = 0; i < (TN + 63) / 64; ++i) {
+        const int q = i * 64 + lane;
+        full |= q < TN && cnt_lds[q] + tile_rows > CAP;
+    }
+    return __any(full);
+}
+
 // Final selection of queries [q0, q0 + nq) of query tile base qt_base and one
 // candidate list per (query, range).
 template <int CAP>
@@ -408,6 +414,7 @@ __device__ __forceinline__ void write_range_lists(int q0, int nq, int qt_base, i
         if (qg >= a.b) continue;  // wave-uniform
         int cq = __builtin_amdgcn_readfirstlane(cnt_lds[q]);
         unsigned long long* buf = my_buf + (size_t)q * CAP;
+        if ((MTR_TIMING(a) & 128) && cq > a.k) cq = a.k;
         if (cq > a.k) {
             compact_query<E>(buf, cq, a.k, 0, floor_lds, cnt_lds, q, lane, shared_floor + q, hist_lds);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -579,6 +586,8 @@ __global__ __launch_bounds__(DYN ? 576 : TM == 256 ? 512 : 256, TM == 256 ? 1 : 
                     if (lane == 0) seq[w] = (int)p;
                 }
                 barrier_keeping_loads();   // the barrier at the tile's end: entry j + 2 is visible from here on
+                // ... and the one in front of a re-selection, which the eight others pass when a buffer is full
+                if (MTR_TIMING(a) & 2 ? false : any_buffer_full<CAP, TN>(cnt_lds, TM, lane)) barrier_keeping_loads();
             }
             __syncthreads();               // ... and the one in front of the final selection
             if (lane == 0) {
@@ -639,11 +648,18 @@ __global__ __launch_bounds__(DYN ? 576 : TM == 256 ? 512 : 256, TM == 256 ? 1 : 
                     const float thr = fmaxf(floor_lds[ql], unorder_f32(order_f32(shared_lds[ql]) - 1u));
 #pragma unroll
                     for (int m = 0; m < MT; ++m)
-                        append_above<CAP, true>(acc[m][n], thr, ql, row_base + m * 32, last_tile, a, cnt_lds, my_buf);
+                        append_above<CAP>(acc[m][n], thr, ql, row_base + m * 32, last_tile, a, cnt_lds, my_buf);
                 }
-                barrier_keeping_loads();  // counts and keys of this tile are visible to the selecting waves
+                barrier_keeping_loads();  // the counts of this tile are visible
                 if (tid < TN) shared_lds[tid] = unorder_f32(pending_floor | (pending_floor == 0 ? 0x007fffffu : 0u));
-                reselect_where_full<CAP>(wave * QPW, QPW, TM, lane, a, floor_lds, cnt_lds, my_buf, shared_floor, hist_lds);
+                if (MTR_TIMING(a) & 2 ? false : any_buffer_full<CAP, TN>(cnt_lds, TM, lane)) {
+                    // ... and, only when a buffer has to be re-selected, the keys: every wave waits
+                    // for its stores (and with them for its loads in flight, which is why the
+                    // appends themselves do not wait) in front of one more barrier.
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    barrier_keeping_loads();
+                    reselect_where_full<CAP>(wave * QPW, QPW, TM, lane, a, floor_lds, cnt_lds, my_buf, shared_floor, hist_lds);
+                }
                 ks = 0;
                 ptile = queued;
             } else {
@@ -703,11 +719,18 @@ __global__ __launch_bounds__(DYN ? 576 : TM == 256 ? 512 : 256, TM == 256 ? 1 : 
                     const float thr = fmaxf(floor_lds[ql], unorder_f32(order_f32(shared_lds[ql]) - 1u));
 #pragma unroll
                     for (int m = 0; m < MT; ++m)
-                        append_above<CAP, true>(acc[m][n], thr, ql, row_base + m * 32, last_tile, a, cnt_lds, my_buf);
+                        append_above<CAP>(acc[m][n], thr, ql, row_base + m * 32, last_tile, a, cnt_lds, my_buf);
                 }
-                barrier_keeping_loads();  // counts and keys of this tile are visible to the selecting waves
+                barrier_keeping_loads();  // the counts of this tile are visible
                 if (tid < TN) shared_lds[tid] = unorder_f32(pending_floor | (pending_floor == 0 ? 0x007fffffu : 0u));
-                reselect_where_full<CAP>(wave * QPW, QPW, TM, lane, a, floor_lds, cnt_lds, my_buf, shared_floor, hist_lds);
+                if (MTR_TIMING(a) & 2 ? false : any_buffer_full<CAP, TN>(cnt_lds, TM, lane)) {
+                    // ... and, only when a buffer has to be re-selected, the keys: every wave waits
+                    // for its stores (and with them for its loads in flight, which is why the
+                    // appends themselves do not wait) in front of one more barrier.
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    barrier_keeping_loads();
+                    reselect_where_full<CAP>(wave * QPW, QPW, TM, lane, a, floor_lds, cnt_lds, my_buf, shared_floor, hist_lds);
+                }
                 ks = 0;
                 ++tile;
                 ptile = phys(tile);
@@ -800,7 +823,7 @@ __global__ __launch_bounds__(DYN ? 576 : TM == 256 ? 512 : 256, TM == 256 ? 1 : 
                 const float thr = fmaxf(floor_lds[ql], unorder_f32(order_f32(shared_lds[ql]) - 1u));
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
-                    append_above<CAP, false>(acc[m][n], thr, ql, row_base + m * 32, last_tile, a, cnt_lds, my_buf);
+                    append_above<CAP>(acc[m][n], thr, ql, row_base + m * 32, last_tile, a, cnt_lds, my_buf);
             }
         }
         __syncthreads();
@@ -1055,31 +1078,54 @@ hipError_t launch_score_mfma(const void* rows, int dtype, int64_t n, int ld, con
 namespace {
 // One wave per query: the k-th largest of its per-tile best scores.  Each of
 // those k tiles holds a row scoring at least that much, so no row below it can
-// be among the query's k best: it becomes the query's starting floor.
+// be among the query's k best: it becomes the query's starting floor.  Samples of
+// more than kMaxSampleKeys tiles are taken `group` neighbouring tiles at a time
+// (the best score of the group: still one row each, so the bound holds).
 template <int E>
-__global__ __launch_bounds__(64) void floor_from_tile_max_kernel(const unsigned int* tile_max, int n_tiles, int k,
+__global__ __launch_bounds__(64) void floor_from_tile_max_kernel(const unsigned int* tile_max, int n_tiles, int group, int k,
                                                                  unsigned int* shared_floor) {
+    __shared__ unsigned int hist[256];
     const int q = blockIdx.x;
     const int lane = threadIdx.x;
+    const unsigned int* mine = tile_max + (size_t)q * n_tiles;
     unsigned long long key[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-        const int t = e * 64 + lane;
-        // the tile number makes equal scores distinct keys; 0 marks an empty slot
-        key[e] = t < n_tiles ? ((unsigned long long)tile_max[(size_t)q * n_tiles + t] << 32) | (unsigned int)(t + 1) : 0ull;
+        const int slot = e * 64 + lane;
+        unsigned int best = 0u;
+        for (int g = 0; g < group; ++g) {
+            const int t = slot * group + g;
+            if (t < n_tiles) best = max(best, mine[t]);
+        }
+        // the slot number makes equal scores distinct keys; 0 marks an empty slot
+        key[e] = best != 0u ? ((unsigned long long)best << 32) | (unsigned int)(slot + 1) : 0ull;
     }
-    const unsigned long long cut = wave_kth_largest<E>(key, k);
-    if (lane == 0) shared_floor[q] = (unsigned int)(cut >> 32);  // 0 (fewer than k+1 tiles): no floor
+    int passes = 0;
+    const unsigned long long cut = wave_kth_largest_hist<E>(key, k, 0, hist, lane, &passes);
+    // The walk stops once exactly k keys are at or above the cut, which may leave the cut's
+    // low bytes open: the k-th largest itself is the smallest of those k.
+    unsigned long long kth = ~0ull;
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+        if (key[e] != 0ull && key[e] >= cut && key[e] < kth) kth = key[e];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const unsigned long long o = __shfl_xor(kth, off, 64);
+        kth = o < kth ? o : kth;
+    }
+    if (lane == 0) shared_floor[q] = cut != 0ull ? (unsigned int)(kth >> 32) : 0u;  // at most k tiles: no floor
 }
 }  // namespace
 
 hipError_t launch_floor_from_tile_max(const unsigned int* tile_max, int n_tiles, int b, int k,
                                       unsigned int* shared_floor, hipStream_t stream) {
-    if (n_tiles > kMaxSampleTiles) return hipErrorInvalidValue;
-    if (n_tiles <= 256)
-        hipLaunchKernelGGL(floor_from_tile_max_kernel<4>, dim3(b), dim3(64), 0, stream, tile_max, n_tiles, k, shared_floor);
+    if (n_tiles < 1 || n_tiles > kMaxSampleTiles) return hipErrorInvalidValue;
+    const int group = (n_tiles + kMaxSampleKeys - 1) / kMaxSampleKeys;
+    const int slots = (n_tiles + group - 1) / group;
+    if (slots <= 256)
+        hipLaunchKernelGGL(floor_from_tile_max_kernel<4>, dim3(b), dim3(64), 0, stream, tile_max, n_tiles, group, k, shared_floor);
     else
-        hipLaunchKernelGGL(floor_from_tile_max_kernel<16>, dim3(b), dim3(64), 0, stream, tile_max, n_tiles, k, shared_floor);
+        hipLaunchKernelGGL(floor_from_tile_max_kernel<16>, dim3(b), dim3(64), 0, stream, tile_max, n_tiles, group, k, shared_floor);
     return hipGetLastError();
 }
 

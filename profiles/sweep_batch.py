@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Batch-size sweep on one GPU: queries/s and time per search for B = 1 .. 4096
 over one synthetic corpus, to locate the hand-over from the HBM-bound scan to the
-matrix-core kernel.  usage: sweep_batch.py [rows dim store k] -> JSON on stdout"""
+matrix-core kernel.  Each point carries the roof that binds it (the longer of one
+pass over the rows at the HBM peak and the multiply-adds at the dense matrix peak
+of the store type) and the fraction of it reached.
+usage: sweep_batch.py [rows dim store k] -> JSON on stdout"""
 import json
 import os
 import sys
@@ -37,9 +40,14 @@ def main():
             shard.search_device(q, k=k)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
+        t_hbm = rows * dim * esize / (bench.HBM_PEAK_GBS * 1e9)
+        t_mfma = 2.0 * b * rows * dim / (bench.MFMA_PEAK_TFLOPS[store] * 1e12)
         out["points"].append({"batch": b, "ms_per_search": dt * 1e3, "queries_per_s": b / dt,
                               "corpus_passes_GBps": rows * dim * esize / dt / 1e9,
-                              "tflops": 2.0 * b * rows * dim / dt / 1e12})
+                              "tflops": 2.0 * b * rows * dim / dt / 1e12,
+                              "binding_roof": "hbm" if t_hbm >= t_mfma else "mfma",
+                              "roof_ms": max(t_hbm, t_mfma) * 1e3,
+                              "frac_of_binding_roof": max(t_hbm, t_mfma) / dt})
     print(json.dumps(out))
 
 
