@@ -1010,7 +1010,7 @@ const TuningField kTuningFields[] = {
     {"mfma_min_batch", &mtr::Tuning::mfma_min_batch},     {"mfma_tnq", &mtr::Tuning::mfma_tnq},
     {"mfma_per_cu", &mtr::Tuning::mfma_per_cu},           {"mfma_cap", &mtr::Tuning::mfma_cap},
     {"mfma_sample_stride", &mtr::Tuning::mfma_sample_stride}, {"mfma_stream_rows", &mtr::Tuning::mfma_stream_rows},
-    {"mfma_interleave", &mtr::Tuning::mfma_interleave},   {"mfma_dynamic_tail", &mtr::Tuning::mfma_dynamic_tail},
+    {"mfma_interleave", &mtr::Tuning::mfma_interleave},   {"mfma_dynamic_tail", &mtr::Tuning::mfma_dynamic_tail}, {"mfma_via_regs", &mtr::Tuning::mfma_via_regs},
     {"mfma_static_permille", &mtr::Tuning::mfma_static_permille},   {"mfma_stages", &mtr::Tuning::mfma_stages},           {"mfma_tile_rows", &mtr::Tuning::mfma_tile_rows},
     {"wide_min_batch", &mtr::Tuning::wide_min_batch},     {"wide_qgroup", &mtr::Tuning::wide_qgroup},
     {"scan_short_lists", &mtr::Tuning::scan_short_lists},

@@ -58,6 +58,7 @@ struct Tuning {
     int mfma_dynamic_tail = -1;   // -1: the tall ring forms claim their last tiles from a counter; 0 / 1
     int mfma_static_permille = 0; // ... share of the tiles taken by index in that form (0: 930)
     int mfma_interleave = -1;     // -1: ranges interleaved tile by tile when one query tile streams a large shard; 0 / 1
+    int mfma_via_regs = -1;       // -1: the tall ring form's 128-query tile takes its rows through registers; 0 never; 1 the 64-query tile too
     int wide_min_batch = 129;     // smallest batch for the 256 x 256-tile kernel
     int wide_qgroup = 0;          // its query tiles per row list on one XCD (0: four)
     int scan_wg_per_cu = 0;       // scan workgroups per CU (0: one for a single query, occupancy otherwise)
@@ -172,6 +173,7 @@ struct MfmaPlan {
     int interleave;           // row ranges interleaved tile by tile instead of contiguous stretches
     int dynamic_tail;         // ... and the last tiles claimed from a device-wide counter (needs MfmaPass::sync)
     long long static_tiles;   // tiles every range takes by index in that form
+    int via_regs;             // tall ring form with the rows in flight in registers instead of LDS stages
 };
 
 // Launch shape of the matrix-core scoring kernel; -1 when the shape is not

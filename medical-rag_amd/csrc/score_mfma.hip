@@ -41,6 +41,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "mtr_device.h"
 #include "wave_select.h"
 
@@ -278,12 +280,52 @@ __device__ __forceinline__ void compact_query(unsigned long long* buf, int c, in
 
 // ---- pieces of the fused top-k shared by the tile shapes ---------------------
 
+// LDS stores and the LDS atomic of an append, written as assembly for the kernel form that
+// keeps rows in flight in registers.  The compiler orders every LDS store or atomic it can
+// see behind ALL direct-to-LDS loads the wave has in flight (s_waitcnt vmcnt(0) in front of
+// it: for all it knows the two write the same bytes), and with it behind every register
+// load issued before them -- which would drain that form's queue of row loads at every
+// step.  The stage buffers, the counts and the floors are different bytes; an instruction
+// the compiler cannot look into gets no such wait.  (LDS operations of one wave complete in
+// order, and every reader of another wave sits behind `s_waitcnt lgkmcnt(0)` + s_barrier.)
+__device__ __forceinline__ unsigned int lds_address(const void* p) { return (unsigned int)(size_t)(lds_ptr_t)p; }
+template <int OFFSET>
+__device__ __forceinline__ void lds_store_b128(unsigned int addr, const u32x4& v) {
+    asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFFSET) : "memory");
+}
+// A streaming 16-byte load the compiler does not track: it returns at once as far as the
+// compiler knows, so the CALLER must not let anything read `dst` before a counted
+// s_waitcnt of its own has covered the load (the compiler's own waits for loads it does
+// track came out as vmcnt(0) inside the loop that keeps four steps in flight).
+__device__ __forceinline__ void load_b128_untracked(u32x4& dst, const char* src) {
+    asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(src) : "memory");
+}
+// "score > own floor && score >= shared floor" as one strict threshold, from the shared
+// floor word as published (order-preserving score bits, 0: none yet): v >= sh is
+// v > (largest float below sh); with no floor the bits stand for a NaN, which loses the fmaxf.
+__device__ __forceinline__ float strict_threshold(float own, unsigned int known) {
+    const unsigned int ord = known | (known == 0u ? 0x007fffffu : 0u);
+    return fmaxf(own, unorder_f32(ord - 1u));
+}
+// The shared floors of up to 64 queries, one per active lane, from global memory (read at
+// the device's coherence point: other workgroups raise them with atomics) straight into
+// the LDS words dst[lane]: no register result, so nothing the compiler would wait for.
+// Whatever a reader finds there, old or new, is a floor some row range has published.
+__device__ __forceinline__ void fetch_floors(const unsigned int* src, unsigned int* dst) {
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)dst, 4, 0, 16 /* sc1: device scope */);
+}
+__device__ __forceinline__ int lds_add_return(int* p, int v) {
+    int old;
+    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(old) : "v"(lds_address(p)), "v"(v) : "memory");
+    return old;
+}
+
 // One 32 x 32 MFMA tile of finished scores (one query per lane column, 16 rows
 // per lane: row0 + (r & 3) + 8 * (r >> 2) for register r): appends what is
 // above the query's threshold to its candidate buffer and clears the tile.
 // The wave does not wait for its stores: whoever reads the keys (a re-selection,
 // the final selection) has every wave wait in front of a barrier first.
-template <int CAP>
+template <int CAP, bool ASM_ATOMIC = false>
 __device__ __forceinline__ void append_above(f32x16& tile, float thr, int ql, long long row0, bool last_tile,
                                              const MfmaArgs& a, int* cnt_lds, unsigned long long* my_buf) {
     // registers 4 g .. 4 g + 3 hold rows row0 + 8 g .. + 3
@@ -310,7 +352,7 @@ __device__ __forceinline__ void append_above(f32x16& tile, float thr, int ql, lo
                     const bool hit = tile[4 * g + j] > thr && 8 * g + j < rows_left;
                     if (__any(hit)) {
                         if (hit) {
-                            int slot = atomicAdd(&cnt_lds[ql], 1);
+                            int slot = ASM_ATOMIC ? lds_add_return(&cnt_lds[ql], 1) : atomicAdd(&cnt_lds[ql], 1);
                             if (MTR_TIMING(a) & 4) atomicAdd(a.debug_counters, 1ull);
                             if (MTR_TIMING(a) & 2) slot &= CAP - 1;
                             if (slot < CAP && !(MTR_TIMING(a) & 8)) dst[slot] = pack_key(tile[4 * g + j], (int)(row0 + 8 * g + j));
@@ -458,8 +500,25 @@ __device__ __forceinline__ void write_range_lists(int q0, int nq, int qt_base, i
 // the claims -- an atomic issued by a loading wave would sit in front of its
 // counted waits -- and hands the tile numbers on through LDS; it takes part in
 // every barrier of the eight others and does nothing else.
-template <typename T, int CAP, int TNQ, bool MAX_ONLY, int ROW_AUX, int NS, int TM = kTileRows, bool DYN = false>
+// REGS (tall ring form, bf16, 64- and 128-query tiles, rows of whole 512 bytes): the rows
+// travel through registers.  With direct-to-LDS loads the bytes in flight are the LDS
+// ring, two K steps of rows (64 KB a CU), and at 128 queries a step's MFMAs and fragment
+// reads are long enough that two steps no longer cover a load's way through the memory
+// system (10M x 1024: 3.75 ms with, 2.98 ms without the MFMAs).  Here every wave keeps
+// kRegDepth K steps of its own row pieces in flight in registers (16 registers a step;
+// 128 KB a CU at depth four), writes step s + 1 into one of TWO row stages right behind the
+// barrier of step s and asks for step s + 1 + depth in the same breath; only the query
+// tile still comes by direct-to-LDS loads, into a ring of depth + 1 stages and as far
+// ahead as the rows, because a wave's loads complete in order: waiting for a young query
+// piece would wait for every older row load too.  Past its last tile a workgroup keeps
+// requesting (from the query matrix, which is in L2) so that no load sits behind a branch.
+constexpr int kRegDepth = 4;
+constexpr int lds_bytes_regs(int tnq) { return 2 * 256 * kStepBytes + (kRegDepth + 1) * tnq * kStepBytes + tnq * 12 + 8 * 1024 + tnq * 4; }
+
+template <typename T, int CAP, int TNQ, bool MAX_ONLY, int ROW_AUX, int NS, int TM = kTileRows, bool DYN = false, bool REGS = false>
 __global__ __launch_bounds__(DYN ? 576 : TM == 256 ? 512 : 256, TM == 256 ? 1 : 2) void score_topk_mfma_kernel(MfmaArgs a) {
+    static_assert(!REGS || (NS == 3 && TM == 256 && !MAX_ONLY && !DYN && sizeof(T) == 2 && TNQ % 64 == 0 && ROW_AUX == 2),
+                  "rows through registers: tall ring form, bf16, 64 or 128 queries, streaming loads");
     static_assert(!DYN || (NS == 3 && TM == 256 && !MAX_ONLY), "claimed tiles exist in the tall ring form only");
     static_assert(NS == 2 || (NS == 3 && !MAX_ONLY), "the ring form exists for the full launch only");
     static_assert(TM == 128 || (TM == 256 && NS == 3), "the tall tile exists in the ring form only");
@@ -483,7 +542,8 @@ __global__ __launch_bounds__(DYN ? 576 : TM == 256 ? 512 : 256, TM == 256 ? 1 : 
     static_assert((CAP & (CAP - 1)) == 0, "CAP must be a power of two");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const stage0 = smem;
-    float* floor_lds = reinterpret_cast<float*>(smem + NS * kStageBytes);  // own k-th best score (strict)
+    constexpr int kFrontBytes = REGS ? 2 * TM * kStepBytes + (kRegDepth + 1) * TNQ * kStepBytes : NS * kStageBytes;
+    float* floor_lds = reinterpret_cast<float*>(smem + kFrontBytes);  // own k-th best score (strict)
     int* cnt_lds = reinterpret_cast<int*>(floor_lds + TN);
     float* shared_lds = reinterpret_cast<float*>(cnt_lds + TN);           // best floor of ANY range (non-strict)
     unsigned int* hist_lds = reinterpret_cast<unsigned int*>(shared_lds + TN) + (threadIdx.x >> 6) * 256;
@@ -546,6 +606,128 @@ __global__ __launch_bounds__(DYN ? 576 : TM == 256 ? 512 : 256, TM == 256 ? 1 : 
         for (int n = 0; n < NQ16; ++n) acc16[m][n] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
     const long long total_steps = my_tiles * ksteps;
+    if constexpr (REGS) {
+        constexpr int D = kRegDepth;               // K steps of row loads in flight per wave
+        constexpr int QR = D + 1;                  // stages of the query ring
+        constexpr int RP = TM / (8 * WAVES);       // 8-row pieces per wave and step (4)
+        constexpr int QP = TNQ / (8 * WAVES);      // query pieces per wave and step (1 or 2)
+        constexpr int kRowStage = TM * kStepBytes, kQStage = TNQ * kStepBytes;
+        static_assert(RP * WAVES * 8 == TM && QP * WAVES * 8 == TNQ && D == 4, "equal shares, four register sets");
+        if (my_tiles > 0) {   // workgroup-uniform
+            char* const qstage = smem + 2 * kRowStage;
+            // this wave's pieces of a row stage: piece i at +i KB, lane-linear as a direct-to-LDS load would write it
+            const unsigned int row_dst = lds_address(smem) + (unsigned int)(wave * RP * 1024 + lane * 16);
+            // the shared floors as fetched (raw words), behind the eight waves' histograms
+            unsigned int* const fetched_lds = reinterpret_cast<unsigned int*>(shared_lds + TN) + WAVES * 256;
+            for (int i = tid; i < TN; i += kThreads) fetched_lds[i] = order_f32(shared_lds[i]);
+            const int chunk16 = ((lane & 7) ^ (lane >> 3)) * 16;
+            u32x4 regs[D][RP];
+            const char* rp[RP];          // this lane's source of each piece, K step 0 of the tile being requested
+            long long ld_t = 0;          // ... which is the workgroup's ld_t-th tile
+            int ld_ks = 0;
+            auto set_sources = [&](long long t) {
+                const bool real = t < my_tiles;
+                const long long pt = real ? phys(tile_lo + t) : 0;
+#pragma unroll
+                for (int i = 0; i < RP; ++i) {
+                    const int r = (wave * RP + i) * 8 + (lane >> 3);
+                    long long row = pt * TM + r;
+                    row = row < a.n - 1 ? row : a.n - 1;
+                    const char* src = a.rows + row * row_bytes;
+                    const char* idle = qbase + (long long)(r % TN) * row_bytes;
+                    rp[i] = (real ? src : idle) + chunk16;
+                }
+            };
+            auto request_rows = [&](u32x4 (&set)[RP]) {
+#pragma unroll
+                for (int i = 0; i < RP; ++i) load_b128_untracked(set[i], rp[i] + ld_ks * kStepBytes);
+                if (++ld_ks == ksteps) {
+                    ld_ks = 0;
+                    set_sources(++ld_t);
+                }
+            };
+            int q_ks = 0, q_stage = 0;   // request cursor of the query ring
+            auto request_queries = [&]() {
+                stage_tile<0, TNQ, WAVES>(qbase, 0, TN - 1, row_bytes, q_ks * kStepBytes, qstage + q_stage * kQStage, wave, lane);
+                q_ks = q_ks + 1 == ksteps ? 0 : q_ks + 1;
+                q_stage = q_stage + 1 == QR ? 0 : q_stage + 1;
+            };
+            int q_cur = 0;               // the stage the MFMAs read
+            // One K step; J = step % 4 picks the register set and the row stage at compile time.
+            auto step = [&](auto jc) {
+                constexpr int J = decltype(jc)::value;
+                constexpr int SET = (J + 1) % D;
+                // the query pieces of this step have landed (this wave's share; the barrier extends it to
+                // all), and so has every row load older than them: those of step s + 1 among them
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * (RP + QP)) : "memory");
+                barrier_keeping_loads();
+                // every wave is past the MFMAs of step s - 1: its row stage takes step s + 1 ...
+#pragma unroll
+                for (int i = 0; i < RP; ++i) {
+                    if constexpr (((J + 1) & 1) == 0) lds_store_b128<0>(row_dst + i * 1024, regs[SET][i]);
+                    else lds_store_b128<kRowStage>(row_dst + i * 1024, regs[SET][i]);
+                }
+                // ... its registers step s + 1 + D, and the query stage of step s - 1 step s + D
+                request_rows(regs[SET]);
+                request_queries();
+                mfma_step<MT, NT>(T{}, smem + (J & 1) * kRowStage, qstage + q_cur * kQStage, row_off, q_off, lane, acc);
+                q_cur = q_cur + 1 == QR ? 0 : q_cur + 1;
+            };
+            // Nothing but the loads below may be in flight when the counted waits start.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            set_sources(0);
+            request_rows(regs[0]);
+            request_rows(regs[1]);
+            request_queries();
+            request_rows(regs[2]);
+            request_queries();
+            request_rows(regs[3]);
+            request_queries();
+            // step "-1": the first step's rows go into stage 0
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * (RP + QP)) : "memory");
+#pragma unroll
+            for (int i = 0; i < RP; ++i) lds_store_b128<0>(row_dst + i * 1024, regs[0][i]);
+            request_rows(regs[0]);
+            request_queries();
+            for (long long t = 0; t < my_tiles; ++t) {
+                const long long ptile = phys(tile_lo + t);
+                // the floors the other ranges have published by now: one load more in this wave's queue,
+                // so the counted waits of the next three steps insist on one row load of three steps ago
+                if (tid < TN) fetch_floors(shared_floor + tid, fetched_lds + (wave << 6));
+                int kg = 0;
+                do {
+                    step(std::integral_constant<int, 0>{});
+                    step(std::integral_constant<int, 1>{});
+                    step(std::integral_constant<int, 2>{});
+                    step(std::integral_constant<int, 3>{});
+                    kg += D;
+                } while (kg < ksteps);
+                const long long row_base = ptile * TM + row_off + 4 * (lane >> 5);
+                const bool last_tile = (ptile + 1) * TM > a.n;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const int ql = q_off + n * 32 + (lane & 31);
+                    const float thr = strict_threshold(floor_lds[ql], fetched_lds[ql]);
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+                        append_above<CAP, true>(acc[m][n], thr, ql, row_base + m * 32, last_tile, a, cnt_lds, my_buf);
+                }
+                barrier_keeping_loads();  // the counts of this tile are visible
+                if (any_buffer_full<CAP, TN>(cnt_lds, TM, lane)) {
+                    // only when a buffer has to be re-selected, the keys: every wave waits for its
+                    // stores (and with them for everything it has in flight) in front of one more barrier
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    barrier_keeping_loads();
+                    reselect_where_full<CAP>(wave * QPW, QPW, TM, lane, a, floor_lds, cnt_lds, my_buf, shared_floor, hist_lds);
+                }
+            }
+            // the requests made past the last tile still land in registers the code below is free to reuse
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        write_range_lists<CAP>(wave * QPW, QPW, qt * TN, range, lane, a, floor_lds, cnt_lds, my_buf, shared_floor, hist_lds);
+        return;
+    }
     if constexpr (DYN) {
         constexpr int LPS_ROWS = TM / (8 * WAVES);
         constexpr bool kUnevenQ = TNQ < 8 * WAVES;
@@ -959,6 +1141,19 @@ int plan_mfma(int dtype, int64_t n, int ld, int b, int k, int num_cus, int sampl
             plan->lds += 16;   // the claimer's four-entry tile ring
         }
     }
+    // Rows through registers (64- and 128-query tiles of the tall ring form, rows of whole 512 bytes).
+    plan->via_regs = 0;
+    {
+        const bool can = plan->stream_rows && tm == 256 && plan->stages == 3 && dtype == 2 && (plan->tnq == 64 || plan->tnq == 128) &&
+                         ((long long)ld * esize) % (kRegDepth * kStepBytes) == 0;
+        const bool want = tn.mfma_via_regs >= 0 ? tn.mfma_via_regs != 0 : plan->tnq == 128;
+        if (can && want) {
+            plan->via_regs = 1;
+            plan->dynamic_tail = 0;
+            plan->static_tiles = 0;
+            plan->lds = lds_bytes_regs(plan->tnq);
+        }
+    }
     plan->cand_bytes = (size_t)plan->grid * plan->tnq * plan->cap * 8;
     return 0;
 }
@@ -1054,6 +1249,8 @@ hipError_t launch_score_mfma(const void* rows, int dtype, int64_t n, int ld, con
 #undef MTR_MFMA_PICK16
     if (plan.tm == 256) {
         if (plan.stages != 3 || plan.cap != 512 || dtype != 2 || a.tile_max != nullptr) return hipErrorInvalidValue;
+        if (plan.via_regs && plan.tnq == 64) return launch(&score_topk_mfma_kernel<bf16_t, 512, 64, false, 2, 3, 256, false, true>);
+        if (plan.via_regs && plan.tnq == 128) return launch(&score_topk_mfma_kernel<bf16_t, 512, 128, false, 2, 3, 256, false, true>);
         if (dyn && plan.tnq == 32) return launch(&score_topk_mfma_kernel<bf16_t, 512, 32, false, 2, 3, 256, true>);
         if (dyn && plan.tnq == 64) return launch(&score_topk_mfma_kernel<bf16_t, 512, 64, false, 2, 3, 256, true>);
         if (plan.tnq == 32) return launch(&score_topk_mfma_kernel<bf16_t, 512, 32, false, 2, 3, 256>);

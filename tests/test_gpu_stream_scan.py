@@ -152,3 +152,44 @@ def test_matrix_core_ring_with_claimed_tail(native, n, d, b):
             torch.cuda.synchronize()
             assert torch.equal(ei, di) and torch.equal(es, ds)
     shard.close()
+
+
+@pytest.mark.parametrize("n,d,b,k", [(300_011, 256, 128, 10), (150_000, 512, 100, 24), (290_000, 256, 64, 10),
+                                     (70_001, 768, 65, 100), (1_000, 256, 128, 10), (200_000, 1024, 40, 5)])
+def test_matrix_core_ring_with_rows_through_registers(native, n, d, b, k):
+    """The tall ring form whose rows stay in flight in registers (four K steps per
+    wave, written into two LDS stages a step ahead; the query tile in a ring of
+    five), forced onto small shards: integer rows, so ids and scores equal the
+    oracle bit for bit; on real-valued rows the same bits as the form that loads
+    rows straight into LDS (same order of a row's products); with and without a
+    sampling launch; searched three times in a row; a shard of fewer tiles than
+    workgroups and a ragged last tile included."""
+    import torch
+    rng = np.random.default_rng(n + d + b)
+    forms = dict(mfma_stream_rows=1, mfma_stages=3, mfma_tile_rows=256, mfma_dynamic_tail=0)
+    corpus = rng.integers(-3, 4, size=(n, d)).astype(np.float32)
+    queries = rng.integers(-3, 4, size=(b, d)).astype(np.float32)
+    corpus[n - 1] = queries[0]
+    shard = native.DeviceShard.from_host(corpus, store_dtype="bf16", normalize=False)
+    want_i, want_s = orc.search(queries, corpus, k, metric="ip")
+    for stride in (0, 3):
+        with native.options(mfma_via_regs=1, mfma_sample_stride=stride, **forms):
+            for _ in range(2):
+                idx, score = shard.search(queries, k=k, metric="ip")
+                assert shard.last_kernel() == "score_topk_mfma_kernel"
+                assert (idx == want_i).all(), (n, d, b, stride)
+                assert (score == want_s.astype(np.float32)).all(), (n, d, b, stride)
+    shard.close()
+    gen = torch.Generator(device="cuda").manual_seed(n)
+    rows = torch.randn((n, d), generator=gen, device="cuda")
+    q = torch.randn((b, d), generator=gen, device="cuda")
+    shard = native.DeviceShard.alloc(n, d, store_dtype="bf16")
+    shard.load_device(0, rows)
+    with native.options(mfma_via_regs=0, mfma_sample_stride=0, **forms):
+        ei, es = (t.clone() for t in shard.search_device(q, k=k))
+    with native.options(mfma_via_regs=1, mfma_sample_stride=0, **forms):
+        for _ in range(3):
+            di, ds = (t.clone() for t in shard.search_device(q, k=k))
+            torch.cuda.synchronize()
+            assert torch.equal(ei, di) and torch.equal(es, ds)
+    shard.close()
