@@ -662,15 +662,17 @@ __global__ __launch_bounds__(DYN ? 576 : TM == 256 ? 512 : 256, TM == 256 ? 1 : 
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * (RP + QP)) : "memory");
                 barrier_keeping_loads();
                 // every wave is past the MFMAs of step s - 1: its row stage takes step s + 1 ...
+                if (!(MTR_TIMING(a) & 64)) {
 #pragma unroll
-                for (int i = 0; i < RP; ++i) {
-                    if constexpr (((J + 1) & 1) == 0) lds_store_b128<0>(row_dst + i * 1024, regs[SET][i]);
-                    else lds_store_b128<kRowStage>(row_dst + i * 1024, regs[SET][i]);
+                    for (int i = 0; i < RP; ++i) {
+                        if constexpr (((J + 1) & 1) == 0) lds_store_b128<0>(row_dst + i * 1024, regs[SET][i]);
+                        else lds_store_b128<kRowStage>(row_dst + i * 1024, regs[SET][i]);
+                    }
                 }
                 // ... its registers step s + 1 + D, and the query stage of step s - 1 step s + D
                 request_rows(regs[SET]);
                 request_queries();
-                mfma_step<MT, NT>(T{}, smem + (J & 1) * kRowStage, qstage + q_cur * kQStage, row_off, q_off, lane, acc);
+                if (!(MTR_TIMING(a) & 32)) mfma_step<MT, NT>(T{}, smem + (J & 1) * kRowStage, qstage + q_cur * kQStage, row_off, q_off, lane, acc);
                 q_cur = q_cur + 1 == QR ? 0 : q_cur + 1;
             };
             // Nothing but the loads below may be in flight when the counted waits start.

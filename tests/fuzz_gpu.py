@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Long randomized parity run on the GPU, beyond what the pytest suite repeats
 every time: random shapes, storage types, row offsets, forced kernel forms
-(streaming loads, ring, 256-row tiles, sampling launch, 256 x 256-tile kernel,
+(streaming loads, ring, 256-row tiles, rows through registers, sampling launch, 256 x 256-tile kernel,
 scan hand-over) and all three search entry points, on small-integer data under
 the inner-product metric, where ids AND scores must equal the numpy oracle bit
 for bit.     usage: python tests/fuzz_gpu.py SEED CASES"""
@@ -17,7 +17,7 @@ t0 = time.time(); fails = 0
 for case in range(cases):
     store = str(rng.choice(["bf16", "fp32"]))
     n = int(rng.choice([1, 3, 127, 128, 129, 255, 256, 257, 511, 1000, 4097, 20000, 60001, 131072]))
-    d = int(rng.choice([1, 8, 32, 33, 64, 100, 128, 192, 200, 256, 300, 320, 768]))
+    d = int(rng.choice([1, 8, 32, 33, 64, 100, 128, 192, 200, 256, 300, 320, 512, 768]))
     b = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 16, 31, 32, 33, 48, 64, 65, 80, 90, 112, 128, 129, 200, 257]))
     k = int(rng.choice([1, 2, 5, 10, 32, 33, 100, 128, 129, 256, 300]))
     opts = {}
@@ -27,6 +27,7 @@ for case in range(cases):
         if rng.random() < 0.3: opts["mfma_tile_rows"] = int(rng.choice([128, 256]))
         if store == "bf16" and rng.random() < 0.3: opts["wide_min_batch"] = 1
         if rng.random() < 0.2: opts["mfma_min_batch"] = int(rng.choice([2, 100]))
+        if rng.random() < 0.5: opts["mfma_via_regs"] = int(rng.integers(0, 2))
     corpus = rng.integers(-3, 4, size=(n, d)).astype(np.float32)
     queries = rng.integers(-3, 4, size=(b, d)).astype(np.float32)
     shard = N.DeviceShard.from_host(corpus, store_dtype=store, normalize=False, row_offset=int(rng.choice([0, 12345])))
