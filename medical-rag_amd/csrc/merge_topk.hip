@@ -40,9 +40,10 @@ struct MergeArgs {
     // Key-list form (merge_select_kernel only): list l of query q holds
     // min(key_counts[...], k_in) entries  row | score bits << 32  instead of (score, id) pairs.
     // Lists come in groups of key_subs (one group per producing workgroup).
-    const unsigned long long* keys;   // [query tile][n_lists / key_subs][256][key_subs][k_in]
-    const unsigned int* key_counts;   // [query tile][n_lists / key_subs][256][key_subs]
+    const unsigned long long* keys;   // [query tile][n_lists / key_subs][key_tile][key_subs][k_in]
+    const unsigned int* key_counts;   // [query tile][n_lists / key_subs][key_tile][key_subs]
     int key_subs;
+    int key_tile;                     // queries per tile
     int* overflow;                    // set to 1 when a count exceeds k_in
     int key_rows;                     // keys of rows >= key_rows (tile padding) are dropped
     const int* run_if;                // not NULL: the kernel does nothing while *run_if == 0
@@ -259,7 +260,7 @@ __global__ void merge_select_kernel(MergeArgs a) {
         // counts with one load, the first two keys of every list with one load each,
         // compacted behind the survivors; only longer lists are then walked one by one.
         auto slot_of = [&](int l) {
-            return (((size_t)(q >> 8) * groups + l / a.key_subs) * 256 + (q & 255)) * a.key_subs + l % a.key_subs;
+            return (((size_t)(q / a.key_tile) * groups + l / a.key_subs) * a.key_tile + q % a.key_tile) * a.key_subs + l % a.key_subs;
         };
         auto stage_key = [&](unsigned long long raw) {
             const int row = (int)(unsigned int)raw;
@@ -604,7 +605,7 @@ hipError_t launch_merge_sorted_lists(const float* cand_s, const int* idx32, int 
                                  idx_offset, out_idx, out_score, stream, nullptr);
     if (b < 1 || k_out < 1 || k_in < 1 || n_lists < 1) return hipErrorInvalidValue;
     MergeArgs a{cand_s, idx32, nullptr, n_lists, list_stride, list_stride, query_stride, k_in, k_out, idx_offset, out_idx, out_score,
-                0, nullptr, nullptr, 1, nullptr, 0, nullptr};
+                0, nullptr, nullptr, 1, 256, nullptr, 0, nullptr};
     hipLaunchKernelGGL(merge_heads_kernel, dim3(b), dim3(kHeadsThreads), lds, stream, a);
     return hipGetLastError();
 }
@@ -615,7 +616,7 @@ hipError_t launch_merge_topk(const float* cand_s, const int* idx32, const long l
                              const int* run_if) {
     if (b < 1 || k_out < 1 || k_in < 1 || n_lists < 1) return hipErrorInvalidValue;
     MergeArgs a{cand_s, idx32, idx64, n_lists, list_stride, list_stride_s, query_stride, k_in, k_out, idx_offset, out_idx, out_score,
-                (n_lists >= 4 * k_out && n_lists >= 128) ? 1 : 0, nullptr, nullptr, 1, nullptr, 0, run_if};
+                (n_lists >= 4 * k_out && n_lists >= 128) ? 1 : 0, nullptr, nullptr, 1, 256, nullptr, 0, run_if};
     const long long total = (long long)n_lists * k_in;
     if (idx32 && k_out <= 256 && total > 64) {
         // one wave per 512-slot chunk of candidates, at most 16
@@ -647,12 +648,13 @@ hipError_t launch_check_short_lists(const float* cand_s, const int* cand_i, int 
     return hipGetLastError();
 }
 
-hipError_t launch_select_keys(const unsigned long long* keys, const unsigned int* counts, int n_lists, int subs, int cap,
+hipError_t launch_select_keys(const unsigned long long* keys, const unsigned int* counts, int n_lists, int subs, int tile_queries, int cap,
                               int n_rows, int b, int k_out, long long idx_offset, long long* out_idx, float* out_score,
                               int* overflow, hipStream_t stream) {
-    if (b < 1 || k_out < 1 || k_out > 256 || cap < 1 || n_lists < 1 || subs < 1 || n_lists % subs != 0) return hipErrorInvalidValue;
+    if (b < 1 || k_out < 1 || k_out > 256 || cap < 1 || n_lists < 1 || subs < 1 || n_lists % subs != 0 || tile_queries < 1)
+        return hipErrorInvalidValue;
     MergeArgs a{nullptr, nullptr, nullptr, n_lists, 0, 0, 0, cap, k_out, idx_offset, out_idx, out_score, 0,
-                keys, counts, subs, overflow, n_rows, nullptr};
+                keys, counts, subs, tile_queries, overflow, n_rows, nullptr};
     const int nw = n_lists < 8 ? n_lists : 8;
     const size_t lds_sel = (size_t)nw * kSelSlots * 8 + (size_t)nw * 1024 + (size_t)nw * 4 + 16;
     hipLaunchKernelGGL(merge_select_kernel, dim3(b), dim3(nw * 64), lds_sel, stream, a);

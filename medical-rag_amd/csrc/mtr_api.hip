@@ -361,20 +361,20 @@ int enqueue_mfma(mtr_index* ix, S& sc, const mtr::MfmaPlan& plan, const void* de
     // Queries padded to whole tiles: the sampling launch may cut the batch into tiles of another
     // width than the full launch (fewer rows, narrower tiles), and its padded count can be the larger.
     const int padded_q = std::max(plan.n_qtiles * plan.tnq, stride >= 2 ? samp.n_qtiles * samp.tnq : 0);
-    const int64_t q_rows = std::max<int64_t>((int64_t)padded_q, use_wide ? (int64_t)wide.n_qtiles * 256 : 0);
+    const int64_t q_rows = std::max<int64_t>((int64_t)padded_q, use_wide ? (int64_t)wide.n_qtiles * wide.tq : 0);
     const size_t qbytes = (size_t)q_rows * q_row_bytes;
     const void* q_old = sc.keeps_query_tiles() ? ix->scratch[kQTiles].p : nullptr;
     if ((rc = sc.need(kQTiles, qbytes)) != MTR_OK) return rc;
     if ((rc = sc.need(kMfmaCand, plan.cand_bytes)) != MTR_OK) return rc;
     if ((rc = sc.need(kCandS, (size_t)b * plan.n_ranges * k * 4)) != MTR_OK) return rc;
     if ((rc = sc.need(kCandI, (size_t)b * plan.n_ranges * k * 4)) != MTR_OK) return rc;
-    const int floor_words = std::max(padded_q, use_wide ? wide.n_qtiles * 256 : 0);
+    const int floor_words = std::max(padded_q, use_wide ? wide.n_qtiles * wide.tq : 0);
     if ((rc = sc.need(kMfmaFloor, (size_t)floor_words * 4)) != MTR_OK) return rc;
     size_t tile_max_bytes = 0;
     if (use_wide) {
         if ((rc = sc.need(kWideKeys, wide.key_bytes)) != MTR_OK) return rc;
         if ((rc = sc.need(kWideCounts, (wide.count_words + 1) * 4)) != MTR_OK) return rc;
-        tile_max_bytes = (size_t)wide.n_qtiles * 256 * wide_samp.n_tiles * 4;
+        tile_max_bytes = (size_t)wide.n_qtiles * wide.tq * wide_samp.n_tiles * 4;
     }
     if (stride >= 2) tile_max_bytes = std::max<size_t>(tile_max_bytes, (size_t)floor_words * (size_t)samp.n_tiles * 4);
     if (tile_max_bytes && (rc = sc.need(kTileMax, tile_max_bytes)) != MTR_OK) return rc;
@@ -422,13 +422,13 @@ int enqueue_mfma(mtr_index* ix, S& sc, const mtr::MfmaPlan& plan, const void* de
         overflow = reinterpret_cast<int*>(counts + wide.count_words);
         HIP_TRY(mtr::launch_fill_u32(overflow, 0u, 1, stream));
         // the sampling form raises tile_max with atomic maxima: every word starts at zero (below any score)
-        HIP_TRY(mtr::launch_fill_u32(tile_max, 0u, (size_t)wide.n_qtiles * 256 * wide_samp.n_tiles, stream));
+        HIP_TRY(mtr::launch_fill_u32(tile_max, 0u, (size_t)wide.n_qtiles * wide.tq * wide_samp.n_tiles, stream));
         HIP_TRY(mtr::launch_score_wide(ix->rows, ix->n, ix->ld, qbuf, b, wide_samp, nullptr, nullptr, nullptr, wstride,
                                        tile_max, stream));
         HIP_TRY(mtr::launch_floor_from_tile_max(tile_max, (int)wide_samp.n_tiles, b, k, floors, stream));
         HIP_TRY(mtr::launch_score_wide(ix->rows, ix->n, ix->ld, qbuf, b, wide, floors, keys, counts, 1, nullptr, stream));
         if (profiling) HIP_TRY(hipEventRecord(e1, stream));
-        HIP_TRY(mtr::launch_select_keys(keys, counts, wide.n_lists * mtr::kWideSubs, mtr::kWideSubs, wide.cap, (int)ix->n, b, k, ix->row_offset, dev_out_idx,
+        HIP_TRY(mtr::launch_select_keys(keys, counts, wide.n_lists * mtr::kWideSubs, mtr::kWideSubs, wide.tq, wide.cap, (int)ix->n, b, k, ix->row_offset, dev_out_idx,
                                         dev_out_score, overflow, stream));
         HIP_TRY(mtr::launch_reset_floors_if(floors, floor_words, overflow, stream));
     }
@@ -1012,7 +1012,7 @@ const TuningField kTuningFields[] = {
     {"mfma_sample_stride", &mtr::Tuning::mfma_sample_stride}, {"mfma_stream_rows", &mtr::Tuning::mfma_stream_rows},
     {"mfma_interleave", &mtr::Tuning::mfma_interleave},   {"mfma_dynamic_tail", &mtr::Tuning::mfma_dynamic_tail}, {"mfma_via_regs", &mtr::Tuning::mfma_via_regs},
     {"mfma_static_permille", &mtr::Tuning::mfma_static_permille},   {"mfma_stages", &mtr::Tuning::mfma_stages},           {"mfma_tile_rows", &mtr::Tuning::mfma_tile_rows},
-    {"wide_min_batch", &mtr::Tuning::wide_min_batch},     {"wide_qgroup", &mtr::Tuning::wide_qgroup},
+    {"wide_min_batch", &mtr::Tuning::wide_min_batch},     {"wide_qgroup", &mtr::Tuning::wide_qgroup}, {"wide_tile_queries", &mtr::Tuning::wide_tile_queries},
     {"scan_short_lists", &mtr::Tuning::scan_short_lists},
     {"scan_wg_per_cu", &mtr::Tuning::scan_wg_per_cu},     {"scan_form", &mtr::Tuning::scan_form},
     {"scan_static_permille", &mtr::Tuning::scan_static_permille}, {"scan_pair_permille", &mtr::Tuning::scan_pair_permille},

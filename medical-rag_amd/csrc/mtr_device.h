@@ -58,9 +58,10 @@ struct Tuning {
     int mfma_dynamic_tail = -1;   // -1: the tall ring forms claim their last tiles from a counter; 0 / 1
     int mfma_static_permille = 0; // ... share of the tiles taken by index in that form (0: 930)
     int mfma_interleave = -1;     // -1: ranges interleaved tile by tile when one query tile streams a large shard; 0 / 1
-    int mfma_via_regs = -1;       // -1: the tall ring form's 128-query tile takes its rows through registers; 0 never; 1 the 64-query tile too
+    int mfma_via_regs = -1;       // -1: the tall ring form's 128-query tile, and its 64-query tile where it does not claim its tail, take their rows through registers; 0 never; 1 wherever the shape allows
     int wide_min_batch = 129;     // smallest batch for the 256 x 256-tile kernel
     int wide_qgroup = 0;          // its query tiles per row list on one XCD (0: four)
+    int wide_tile_queries = 0;    // its query-tile width 128 / 192 / 256 (0: the narrowest that keeps the number of tiles)
     int scan_wg_per_cu = 0;       // scan workgroups per CU (0: one for a single query, occupancy otherwise)
     int scan_max_qb = 0;          // most queries per scan pass 1 / 2 / 4 / 8 (0: four)
     int scan_nontemporal = -1;    // -1: streaming row loads on shards beyond the caches; 0 / 1
@@ -213,14 +214,15 @@ hipError_t launch_floor_from_tile_max(const unsigned int* tile_max, int n_tiles,
 
 constexpr int kWideSubs = 8;  // key lists per (workgroup, query): one per lane that holds the query's scores
 struct WidePlan {
-    int n_qtiles;             // query tiles of 256
+    int tq;                   // queries per tile: 128, 192 or 256
+    int n_qtiles;             // query tiles
     int n_lists;              // interleaved row lists (workgroups per query tile)
     long long n_tiles;        // row tiles of 256
     int grid;
     size_t lds;
     int cap;                  // key slots per list; every (workgroup, query) pair has kWideSubs lists
-    size_t key_bytes;         // [n_qtiles][n_lists][256][kWideSubs][cap] packed keys
-    size_t count_words;       // [n_qtiles][n_lists][256][kWideSubs]
+    size_t key_bytes;         // [n_qtiles][n_lists][tq][kWideSubs][cap] packed keys
+    size_t count_words;       // [n_qtiles][n_lists][tq][kWideSubs]
 };
 
 // Launch shape of the 256 x 256-tile filter kernel (bf16 shards, large
@@ -231,14 +233,14 @@ int plan_wide(int dtype, int64_t n, int ld, int b, int k, int expected_hits, int
 // rows x queries on the matrix cores.  tile_max NULL: every score >= its query's
 // floor (floors[q], order-preserving bits as written by
 // launch_floor_from_tile_max) is appended as  row | score bits << 32  to
-// keys[query tile][list][query][sub][0..cap) (rows past n in the last tile
+// keys[query tile][list][query of the tile][sub][0..cap) (rows past n in the last tile
 // included, as copies of the last row), and counts[...][sub] receives how many
 // reached the floor (more than cap: the list is incomplete).  tile_max not
 // NULL (sampling form): tile t of the launch is tile t * tile_stride of the
-// matrix, and tile_max[q][t] ([n_qtiles*256][plan.n_tiles], zeroed by the
+// matrix, and tile_max[q][t] ([n_qtiles*plan.tq][plan.n_tiles], zeroed by the
 // caller) receives each query's best score of the tile.  plan: from plan_wide
 // for the rows the launch covers (its tiles x 256).
-// queries: [n_qtiles*256][ld] bf16, rows past b zero.
+// queries: [n_qtiles*plan.tq][ld] bf16, rows past b zero.
 hipError_t launch_score_wide(const void* rows, int64_t n, int ld, const void* queries, int b, const WidePlan& plan,
                              const unsigned int* floors, unsigned long long* keys, unsigned int* counts,
                              int tile_stride, unsigned int* tile_max, hipStream_t stream);
@@ -266,8 +268,8 @@ hipError_t launch_merge_sorted_lists(const float* cand_s, const int* idx32, int 
 // (score descending, row ascending) order, ignoring keys of rows >= n_rows (the
 // last tile's padding); *overflow is set to 1 when a list of any query was
 // incomplete (the outputs of that query are then not valid).
-// n_lists lists per query in groups of subs ([query tile][n_lists / subs][256][subs][cap]).
-hipError_t launch_select_keys(const unsigned long long* keys, const unsigned int* counts, int n_lists, int subs, int cap,
+// n_lists lists per query in groups of subs ([query tile][n_lists / subs][tile_queries][subs][cap]).
+hipError_t launch_select_keys(const unsigned long long* keys, const unsigned int* counts, int n_lists, int subs, int tile_queries, int cap,
                               int n_rows, int b, int k_out, long long idx_offset, long long* out_idx, float* out_score, int* overflow,
                               hipStream_t stream);
 

@@ -1148,7 +1148,8 @@ int plan_mfma(int dtype, int64_t n, int ld, int b, int k, int num_cus, int sampl
     {
         const bool can = plan->stream_rows && tm == 256 && plan->stages == 3 && dtype == 2 && (plan->tnq == 64 || plan->tnq == 128) &&
                          ((long long)ld * esize) % (kRegDepth * kStepBytes) == 0;
-        const bool want = tn.mfma_via_regs >= 0 ? tn.mfma_via_regs != 0 : plan->tnq == 128;
+        // (the 64-query tile gains 0.3 % where it does not claim its tail, nothing where it does)
+        const bool want = tn.mfma_via_regs >= 0 ? tn.mfma_via_regs != 0 : plan->tnq == 128 || !plan->dynamic_tail;
         if (can && want) {
             plan->via_regs = 1;
             plan->dynamic_tail = 0;

@@ -72,7 +72,7 @@ namespace mtr {
 namespace {
 
 constexpr int kWideThreads = 512;
-constexpr int kWideTile = 256;                  // rows per tile = queries per tile
+constexpr int kWideTile = 256;                  // rows per tile, and the widest query tile
 constexpr int kHalfBytes = 128 * 128;           // 128 rows x 128 bytes
 constexpr int kWideStepBytes = 4 * kHalfBytes;  // rows lo, rows hi, queries lo, queries hi
 constexpr size_t kWideLds = 2 * kWideStepBytes;
@@ -94,17 +94,17 @@ struct WideArgs {
     const char* rows;         // [n][ld] bf16
     long long n;
     int ld;                   // elements, a multiple of 64
-    const char* queries;      // [n_qtiles*256][ld] bf16, zero rows past b
+    const char* queries;      // [n_qtiles*TQ][ld] bf16, zero rows past b (TQ: queries per tile, 128 / 192 / 256)
     int b;
     int n_lists;              // row lists (workgroups per query tile)
     int n_qtiles;
     int qgroup;               // query tiles that share a row list on one XCD (see the kernel)
     long long n_tiles;        // tiles this launch covers (numbered 0.. in its own order)
     int tile_stride;          // tile t of the launch is tile t * tile_stride of the matrix
-    unsigned int* tile_max;   // sampling form: [n_qtiles*256][n_tiles] best score per (query, tile), zeroed by the caller
+    unsigned int* tile_max;   // sampling form: [n_qtiles*TQ][n_tiles] best score per (query, tile), zeroed by the caller
     const unsigned int* floor;    // [b] order-preserving score bits (0: no floor)
-    unsigned long long* keys;     // [n_qtiles][n_lists][256][kWideSubs][cap]: row | (unsigned long long)score bits << 32
-    unsigned int* counts;         // [n_qtiles][n_lists][256][kWideSubs] scores that reached the floor (may exceed cap)
+    unsigned long long* keys;     // [n_qtiles][n_lists][TQ][kWideSubs][cap]: row | (unsigned long long)score bits << 32
+    unsigned int* counts;         // [n_qtiles][n_lists][TQ][kWideSubs] scores that reached the floor (may exceed cap)
     int cap;
     int debug;                // timing experiments only: bit 0 nothing reaches the floor
 };
@@ -127,18 +127,18 @@ __device__ __forceinline__ unsigned int lane_piece_offset(int lane, unsigned int
     return (unsigned int)(lane >> 3) * row_bytes + (unsigned int)(((lane & 7) ^ (lane >> 3)) << 4);
 }
 
-// This wave's share (4 of 32 instructions) of the two query halves of a K step.
+// This wave's share (NN of 8 NN instructions) of the query tile of a K step: 64 NN queries,
+// eight rows a piece, in tile order behind the two row halves.
 // wave: wave-uniform (scalar) wave number.
+template <int NN>
 __device__ __forceinline__ void request_queries(const char* qbase, long long row_bytes, int k0_bytes, char* dst, int wave,
                                                 unsigned int lane_off) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int t = wave * 2 + i;
-            const char* base = scalar_pointer(qbase + (long long)(h * 128 + t * 8) * row_bytes + k0_bytes);
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + lane_off), (lds_ptr_t)(dst + (2 + h) * kHalfBytes + t * 1024), 16, 0, 0);
-        }
+    for (int i = 0; i < NN; ++i) {
+        const int t = wave * NN + i;
+        const char* base = scalar_pointer(qbase + (long long)(t * 8) * row_bytes + k0_bytes);
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + lane_off), (lds_ptr_t)(dst + 2 * kHalfBytes + t * 1024), 16, 0, 0);
+    }
 }
 
 // ... and of ITS GROUP's row half (16 instructions over the group's 4 waves).
@@ -179,13 +179,13 @@ __device__ __forceinline__ void barrier_keeping_loads() {
 // multiply.  The order is pinned with sched_group_barrier; left to itself the
 // compiler issues all reads after all MFMAs and the wave then waits for them.
 // FIRST: the sums start from zero instead of acc.
-template <bool FIRST>
-__device__ __forceinline__ void mfma_low_rows(bf16x8 (&fa)[4][2], const bf16x8 (&fb)[4][2], f32x4 (&acc)[8][4],
+template <bool FIRST, int NN>
+__device__ __forceinline__ void mfma_low_rows(bf16x8 (&fa)[4][2], const bf16x8 (&fb)[NN][2], f32x4 (&acc)[8][NN],
                                               const char* sa, int lane) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
 #pragma unroll
-        for (int nn = 0; nn < 4; ++nn) {
+        for (int nn = 0; nn < NN; ++nn) {
             const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
             f32x4 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m][0], fb[nn][0], FIRST ? zero : acc[m][nn], 0, 0, 0);
             acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m][1], fb[nn][1], c, 0, 0, 0);
@@ -195,36 +195,39 @@ __device__ __forceinline__ void mfma_low_rows(bf16x8 (&fa)[4][2], const bf16x8 (
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);  // eight MFMAs
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // two LDS reads
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * NN, 0);  // the MFMAs of a row tile
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);       // two LDS reads
     }
 }
 
 // ... and of its high rows (row tiles 4-7).  The caller has just requested the
-// eight 1 KiB pieces of a later K step; they are issued one per four MFMAs
+// NN + 4 1 KiB pieces of a later K step; they are issued one per NN MFMAs
 // instead of as a burst in front of them (a piece costs its wave 100-200 cycles
 // of issue, which the matrix cores otherwise spend idle).
-template <bool FIRST>
-__device__ __forceinline__ void mfma_high_rows(const bf16x8 (&fa)[4][2], const bf16x8 (&fb)[4][2], f32x4 (&acc)[8][4]) {
+template <bool FIRST, int NN>
+__device__ __forceinline__ void mfma_high_rows(const bf16x8 (&fa)[4][2], const bf16x8 (&fb)[NN][2], f32x4 (&acc)[8][NN]) {
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int nn = 0; nn < 4; ++nn) {
+        for (int nn = 0; nn < NN; ++nn) {
             const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
             f32x4 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m][0], fb[nn][0], FIRST ? zero : acc[4 + m][nn], 0, 0, 0);
             acc[4 + m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m][1], fb[nn][1], c, 0, 0, 0);
         }
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // one load
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // four MFMAs
+    for (int g = 0; g < NN + 4; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // one load
+        __builtin_amdgcn_sched_group_barrier(0x008, NN, 0);  // NN MFMAs (what is left follows the last load)
     }
 }
 
 // MAX_ONLY: the sampling form (a.tile_max), which keeps nothing but each
 // query's best score per tile.
-template <bool MAX_ONLY>
+// NN: 16-query column tiles per wave; the query tile is TQ = 64 NN wide (256, 192 or 128),
+// so that a batch a little above a multiple of 256 does not pay for 256 more columns.
+template <bool MAX_ONLY, int NN>
 __global__ __launch_bounds__(kWideThreads, 2) void score_filter_wide_kernel(WideArgs a) {
+    constexpr int TQ = 64 * NN;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the load addresses build on it
@@ -254,14 +257,14 @@ __global__ __launch_bounds__(kWideThreads, 2) void score_filter_wide_kernel(Wide
     }
     const int ksteps = a.ld / 64;
     const long long row_bytes = (long long)a.ld * 2;
-    const char* qbase = a.queries + (size_t)qt * kWideTile * row_bytes;
+    const char* qbase = a.queries + (size_t)qt * TQ * row_bytes;
     const long long total = my_tiles * ksteps;
 
-    // This lane's four queries (accumulator column = lane & 15) and their floors.
-    float thr[4];
+    // This lane's NN queries (accumulator column = lane & 15) and their floors.
+    float thr[NN];
 #pragma unroll
-    for (int nn = 0; nn < 4; ++nn) {
-        const int q = qt * kWideTile + wn * 64 + nn * 16 + (lane & 15);
+    for (int nn = 0; nn < NN; ++nn) {
+        const int q = qt * TQ + wn * (16 * NN) + nn * 16 + (lane & 15);
         thr[nn] = __builtin_huge_valf();  // padding queries collect nothing
         if (!MAX_ONLY && q < a.b && !(MTR_TIMING(a) & 1)) {
             const unsigned int f = a.floor[q];
@@ -270,7 +273,8 @@ __global__ __launch_bounds__(kWideThreads, 2) void score_filter_wide_kernel(Wide
     }
     // The floors must have arrived before the first tile load is requested: the
     // loop's counted waits assume that nothing else is in flight.
-    asm volatile("" ::"v"(thr[0]), "v"(thr[1]), "v"(thr[2]), "v"(thr[3]) : "memory");
+#pragma unroll
+    for (int nn = 0; nn < NN; ++nn) asm volatile("" ::"v"(thr[nn]) : "memory");
 
     const unsigned int lane_off = lane_piece_offset(lane, (unsigned int)row_bytes);
     // load cursor: the next K step to request
@@ -278,7 +282,7 @@ __global__ __launch_bounds__(kWideThreads, 2) void score_filter_wide_kernel(Wide
     int ld_ks = 0, ld_buf = 0;
     auto request_step = [&]() {
         char* dst = smem + ld_buf * kWideStepBytes;
-        request_queries(qbase, row_bytes, ld_ks * 128, dst, wave, lane_off);
+        request_queries<NN>(qbase, row_bytes, ld_ks * 128, dst, wave, lane_off);
         request_rows(a.rows, ld_tile * a.tile_stride * kWideTile + wm * 128, a.n - 1, row_bytes, ld_ks * 128,
                      dst + wm * kHalfBytes, wn, lane, lane_off);
         ld_buf ^= 1;
@@ -290,17 +294,17 @@ __global__ __launch_bounds__(kWideThreads, 2) void score_filter_wide_kernel(Wide
     request_step();
     request_step();
 
-    // acc[m][nn]: rows 16 m + 4 (lane / 16) + r of the wave's 128, query 16 nn + lane % 16 of its 64
-    f32x4 acc[8][4];
+    // acc[m][nn]: rows 16 m + 4 (lane / 16) + r of the wave's 128, query 16 nn + lane % 16 of its 16 NN
+    f32x4 acc[8][NN];
 #pragma unroll
     for (int m = 0; m < 8; ++m)
 #pragma unroll
-        for (int nn = 0; nn < 4; ++nn)
+        for (int nn = 0; nn < NN; ++nn)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[m][nn][r] = 0.f;   // (every tile's first K step overwrites them)
 
     // step 0 has landed for everybody; then group 1 falls one barrier behind
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NN + 4) : "memory");
     barrier_keeping_loads();
     if (wm == 1) barrier_keeping_loads();
 
@@ -308,25 +312,27 @@ __global__ __launch_bounds__(kWideThreads, 2) void score_filter_wide_kernel(Wide
     // lane / 16 = 0..3); each of them appends to a list of its own and counts in a
     // register.
     const int sub = wm * 4 + (lane >> 4);
-    unsigned long long* my_keys = a.keys + ((size_t)wgid * kWideTile * kWideSubs + sub) * a.cap;
-    int cnt[4] = {0, 0, 0, 0};
+    unsigned long long* my_keys = a.keys + ((size_t)wgid * TQ * kWideSubs + sub) * a.cap;
+    int cnt[NN];
+#pragma unroll
+    for (int nn = 0; nn < NN; ++nn) cnt[nn] = 0;
     const int cap_mask = a.cap - 1;  // cap is a power of two
     long long tile = tile_first;
     int ks = 0;
     for (long long s = 0; s < total; ++s) {
         const char* buf = smem + (int)(s & 1) * kWideStepBytes;
         const char* sa = buf + wm * kHalfBytes;
-        const char* sb = buf + (2 + (wn >> 1)) * kHalfBytes;
-        const int qrow = (wn & 1) * 64;
+        const char* sb = buf + 2 * kHalfBytes;
+        const int qrow = wn * (16 * NN);
         // this group's rows of step s (its queries were waited for before the previous barrier)
-        if (s > 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (s > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NN + 4) : "memory");
         barrier_keeping_loads();                                   // first barrier of the step
         // Fragment of a 16 x 32 block: lane l holds elements 8 (l / 16) .. +7 of row l % 16.
-        bf16x8 fb[4][2], fa[4][2];
+        bf16x8 fb[NN][2], fa[4][2];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int nn = 0; nn < 4; ++nn) fb[nn][kk] = read_frag(sb, qrow + nn * 16 + (lane & 15), 4 * kk + (lane >> 4));
+            for (int nn = 0; nn < NN; ++nn) fb[nn][kk] = read_frag(sb, qrow + nn * 16 + (lane & 15), 4 * kk + (lane >> 4));
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -337,10 +343,10 @@ __global__ __launch_bounds__(kWideThreads, 2) void score_filter_wide_kernel(Wide
         const bool first = ks == 0;
         const bool tile_done = ks + 1 == ksteps;
         __builtin_amdgcn_s_setprio(1);
-        if (first) mfma_low_rows<true>(fa, fb, acc, sa, lane);
-        else mfma_low_rows<false>(fa, fb, acc, sa, lane);
+        if (first) mfma_low_rows<true, NN>(fa, fb, acc, sa, lane);
+        else mfma_low_rows<false, NN>(fa, fb, acc, sa, lane);
         __builtin_amdgcn_s_setprio(0);
-        // the queries of step s + 1: the older four of the eight loads in flight
+        // the queries of step s + 1: the older NN of the NN + 4 loads in flight
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         barrier_keeping_loads();                                   // third barrier
         // The buffers of step s are free: step s + 2 is requested, its pieces spread
@@ -350,10 +356,10 @@ __global__ __launch_bounds__(kWideThreads, 2) void score_filter_wide_kernel(Wide
         __builtin_amdgcn_s_setprio(1);   // the priority change bounds what the scheduler may interleave: requests go inside it
         if (first) {
             request_step();
-            mfma_high_rows<true>(fa, fb, acc);
+            mfma_high_rows<true, NN>(fa, fb, acc);
         } else {
             request_step();
-            mfma_high_rows<false>(fa, fb, acc);
+            mfma_high_rows<false, NN>(fa, fb, acc);
         }
         __builtin_amdgcn_s_setprio(0);
 
@@ -364,7 +370,7 @@ __global__ __launch_bounds__(kWideThreads, 2) void score_filter_wide_kernel(Wide
             const long long ptile = tile * a.tile_stride;
             if constexpr (MAX_ONLY) {
 #pragma unroll
-                for (int nn = 0; nn < 4; ++nn) {
+                for (int nn = 0; nn < NN; ++nn) {
                     float mx = -__builtin_huge_valf();
 #pragma unroll
                     for (int m = 0; m < 8; ++m)
@@ -373,14 +379,14 @@ __global__ __launch_bounds__(kWideThreads, 2) void score_filter_wide_kernel(Wide
                     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
                     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
                     if (lane < 16)
-                        atomicMax(a.tile_max + ((size_t)qt * kWideTile + wn * 64 + nn * 16 + lane) * a.n_tiles + tile, order_f32(mx));
+                        atomicMax(a.tile_max + ((size_t)qt * TQ + wn * (16 * NN) + nn * 16 + lane) * a.n_tiles + tile, order_f32(mx));
                 }
             } else {
                 const int row_base = (int)(ptile * kWideTile) + wm * 128 + 4 * (lane >> 4);
                 if (!(MTR_TIMING(a) & 4))
 #pragma unroll
-                for (int nn = 0; nn < 4; ++nn) {
-                    const int ql = wn * 64 + nn * 16 + (lane & 15);
+                for (int nn = 0; nn < NN; ++nn) {
+                    const int ql = wn * (16 * NN) + nn * 16 + (lane & 15);
                     unsigned long long* qkeys = my_keys + (size_t)ql * kWideSubs * a.cap;
                     // Three scores per test (v_max3): a branch costs more than the compare,
                     // and with some thousand scores per query reaching the floor, about one
@@ -434,9 +440,9 @@ __global__ __launch_bounds__(kWideThreads, 2) void score_filter_wide_kernel(Wide
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if constexpr (!MAX_ONLY) {
 #pragma unroll
-        for (int nn = 0; nn < 4; ++nn) {
-            const int ql = wn * 64 + nn * 16 + (lane & 15);
-            a.counts[((size_t)wgid * kWideTile + ql) * kWideSubs + sub] = (unsigned int)cnt[nn];
+        for (int nn = 0; nn < NN; ++nn) {
+            const int ql = wn * (16 * NN) + nn * 16 + (lane & 15);
+            a.counts[((size_t)wgid * TQ + ql) * kWideSubs + sub] = (unsigned int)cnt[nn];
         }
     }
 }
@@ -453,7 +459,14 @@ __global__ void reset_floors_if_kernel(unsigned int* floors, int words, const in
 
 int plan_wide(int dtype, int64_t n, int ld, int b, int k, int expected_hits, int num_cus, WidePlan* plan) {
     if (dtype != 2 || ld % 64 != 0 || ld < 128 || b < 1 || k < 1 || k > 256 || n < 1 || n > 0x7fffffffLL) return -1;
+    // The fewest query tiles of at most 256, as narrow (128, 192 or 256) as they can be.
     plan->n_qtiles = (b + kWideTile - 1) / kWideTile;
+    const int per_tile = (b + plan->n_qtiles - 1) / plan->n_qtiles;
+    plan->tq = per_tile <= 128 ? 128 : per_tile <= 192 ? 192 : 256;
+    if (tuning().wide_tile_queries == 128 || tuning().wide_tile_queries == 192 || tuning().wide_tile_queries == 256) {
+        plan->tq = tuning().wide_tile_queries;
+        plan->n_qtiles = (b + plan->tq - 1) / plan->tq;
+    }
     plan->n_tiles = (n + kWideTile - 1) / kWideTile;
     long long lists = num_cus / plan->n_qtiles;  // one workgroup per CU
     if (lists > plan->n_tiles) lists = plan->n_tiles;
@@ -468,10 +481,10 @@ int plan_wide(int dtype, int64_t n, int ld, int b, int k, int expected_hits, int
     while (cap < want && cap < 8192) cap *= 2;
     // ... and at most 4 GiB of lists in all (large shards have long sample strides;
     // their lists are long enough for a smaller margin to do)
-    while (cap > 128 && (size_t)plan->grid * kWideTile * kWideSubs * cap * 8 > ((size_t)4 << 30)) cap /= 2;
+    while (cap > 128 && (size_t)plan->grid * plan->tq * kWideSubs * cap * 8 > ((size_t)4 << 30)) cap /= 2;
     plan->cap = cap;
-    plan->key_bytes = (size_t)plan->grid * kWideTile * kWideSubs * cap * 8;
-    plan->count_words = (size_t)plan->grid * kWideTile * kWideSubs;
+    plan->key_bytes = (size_t)plan->grid * plan->tq * kWideSubs * cap * 8;
+    plan->count_words = (size_t)plan->grid * plan->tq * kWideSubs;
     return 0;
 }
 
@@ -508,8 +521,11 @@ hipError_t launch_score_wide(const void* rows, int64_t n, int ld, const void* qu
         hipLaunchKernelGGL(kernel, dim3(plan.grid), dim3(kWideThreads), plan.lds, stream, a);
         return hipGetLastError();
     };
-    if (tile_max != nullptr) return launch(&score_filter_wide_kernel<true>);
-    return launch(&score_filter_wide_kernel<false>);
+    if (plan.tq == 128) return tile_max != nullptr ? launch(&score_filter_wide_kernel<true, 2>) : launch(&score_filter_wide_kernel<false, 2>);
+    if (plan.tq == 192) return tile_max != nullptr ? launch(&score_filter_wide_kernel<true, 3>) : launch(&score_filter_wide_kernel<false, 3>);
+    if (plan.tq != 256) return hipErrorInvalidValue;
+    if (tile_max != nullptr) return launch(&score_filter_wide_kernel<true, 4>);
+    return launch(&score_filter_wide_kernel<false, 4>);
 }
 
 hipError_t launch_reset_floors_if(unsigned int* floors, int words, const int* flag, hipStream_t stream) {

@@ -653,6 +653,39 @@ def test_wide_tile_kernel_equals_general_kernel(native, b, stride):
     ishard.close()
 
 
+@pytest.mark.parametrize("b", [3, 129, 150, 192, 200, 257, 400, 577])
+def test_wide_tile_kernel_query_tile_widths(native, b):
+    """The 256 x 256-tile kernel also comes with query tiles of 192 and 128 (three and
+    two 16-query column tiles per wave instead of four), so that a batch a little above
+    128 or 256 does not pay for a whole 256-wide tile.  Every width, forced and as
+    planned, on integer rows: ids and scores equal the oracle bit for bit (ties
+    everywhere, ragged last row tile, padding queries); on real-valued rows all widths
+    return the same bits (same instruction, same order of a sum's terms)."""
+    rng = np.random.default_rng(5100 + b)
+    n, d, k = 256 * 90 + 131, 192, 10
+    icorpus = rng.integers(-3, 4, size=(n, d)).astype(np.float32)
+    iqueries = rng.integers(-3, 4, size=(b, d)).astype(np.float32)
+    ishard = native.DeviceShard.from_host(icorpus, store_dtype="bf16", normalize=False)
+    want_i, want_s = orc.search(iqueries, icorpus, k, metric="ip")
+    for width in (0, 128, 192, 256):
+        w_i, w_s = _search_with_env(ishard, iqueries, k, MTR_MFMA_SAMPLE_STRIDE=3, MTR_WIDE_MIN_BATCH=1,
+                                    MTR_WIDE_TILE_QUERIES=width, metric="ip")
+        assert ishard.last_kernel() == "score_filter_wide_kernel"
+        assert (w_i == want_i).all() and (w_s == want_s.astype(np.float32)).all(), (b, width)
+    ishard.close()
+    corpus = rng.standard_normal((n, d)).astype(np.float32)
+    queries = rng.standard_normal((b, d)).astype(np.float32)
+    shard = native.DeviceShard.from_host(corpus, store_dtype="bf16")
+    ref = None
+    for width in (256, 192, 128, 0):
+        got = _search_with_env(shard, queries, k, MTR_MFMA_SAMPLE_STRIDE=3, MTR_WIDE_MIN_BATCH=1, MTR_WIDE_TILE_QUERIES=width)
+        if ref is None:
+            ref = got
+            check_topk(got[0], got[1], orc.scores(queries, corpus), k, 2.0 ** -8)
+        assert (got[0] == ref[0]).all() and (got[1] == ref[1]).all(), (b, width)
+    shard.close()
+
+
 def test_wide_tile_kernel_overflow_falls_back(native):
     """When more scores reach a floor than a key list holds (here: thousands of
     bit-equal rows, which all tie with the floor), the general kernel recomputes
