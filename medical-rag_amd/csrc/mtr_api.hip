@@ -1012,7 +1012,7 @@ const TuningField kTuningFields[] = {
     {"mfma_sample_stride", &mtr::Tuning::mfma_sample_stride}, {"mfma_stream_rows", &mtr::Tuning::mfma_stream_rows},
     {"mfma_interleave", &mtr::Tuning::mfma_interleave},   {"mfma_dynamic_tail", &mtr::Tuning::mfma_dynamic_tail}, {"mfma_via_regs", &mtr::Tuning::mfma_via_regs},
     {"mfma_static_permille", &mtr::Tuning::mfma_static_permille},   {"mfma_stages", &mtr::Tuning::mfma_stages},           {"mfma_tile_rows", &mtr::Tuning::mfma_tile_rows},
-    {"wide_min_batch", &mtr::Tuning::wide_min_batch},     {"wide_qgroup", &mtr::Tuning::wide_qgroup}, {"wide_tile_queries", &mtr::Tuning::wide_tile_queries},
+    {"wide_min_batch", &mtr::Tuning::wide_min_batch},     {"wide_qgroup", &mtr::Tuning::wide_qgroup}, {"wide_tile_queries", &mtr::Tuning::wide_tile_queries}, {"wide_stream_rows", &mtr::Tuning::wide_stream_rows},
     {"scan_short_lists", &mtr::Tuning::scan_short_lists},
     {"scan_wg_per_cu", &mtr::Tuning::scan_wg_per_cu},     {"scan_form", &mtr::Tuning::scan_form},
     {"scan_static_permille", &mtr::Tuning::scan_static_permille}, {"scan_pair_permille", &mtr::Tuning::scan_pair_permille},

@@ -61,6 +61,7 @@ struct Tuning {
     int mfma_via_regs = -1;       // -1: the tall ring form's 128-query tile, and its 64-query tile where it does not claim its tail, take their rows through registers; 0 never; 1 wherever the shape allows
     int wide_min_batch = 129;     // smallest batch for the 256 x 256-tile kernel
     int wide_qgroup = 0;          // its query tiles per row list on one XCD (0: four)
+    int wide_stream_rows = -1;    // -1: its row loads stream (nt) when one query tile reads a shard beyond the caches; 0 / 1
     int wide_tile_queries = 0;    // its query-tile width 128 / 192 / 256 (0: the narrowest that keeps the number of tiles)
     int scan_wg_per_cu = 0;       // scan workgroups per CU (0: one for a single query, occupancy otherwise)
     int scan_max_qb = 0;          // most queries per scan pass 1 / 2 / 4 / 8 (0: four)

@@ -143,6 +143,7 @@ __device__ __forceinline__ void request_queries(const char* qbase, long long row
 
 // ... and of ITS GROUP's row half (16 instructions over the group's 4 waves).
 // Rows past the end of the matrix are fetched as copies of the last row.
+template <int AUX>
 __device__ __forceinline__ void request_rows(const char* rows, long long row0, long long row_max, long long row_bytes,
                                              int k0_bytes, char* dst, int wave_in_group, int lane, unsigned int lane_off) {
 #pragma unroll
@@ -158,7 +159,7 @@ __device__ __forceinline__ void request_rows(const char* rows, long long row0, l
         const int valid = left < 0 ? 0 : left > 7 ? 7 : (int)left;
         const int r = (lane >> 3) < valid ? (lane >> 3) : valid;
         const unsigned int off = (unsigned int)r * (unsigned int)row_bytes + (unsigned int)(((lane & 7) ^ (lane >> 3)) << 4);
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + off), (lds_ptr_t)(dst + t * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + off), (lds_ptr_t)(dst + t * 1024), 16, 0, AUX);
     }
 }
 
@@ -225,7 +226,9 @@ __device__ __forceinline__ void mfma_high_rows(const bf16x8 (&fa)[4][2], const b
 // query's best score per tile.
 // NN: 16-query column tiles per wave; the query tile is TQ = 64 NN wide (256, 192 or 128),
 // so that a batch a little above a multiple of 256 does not pay for 256 more columns.
-template <bool MAX_ONLY, int NN>
+// ROW_AUX: cache-policy bits of the row loads (2 = nt, streaming: a launch with ONE query
+// tile over a shard beyond the caches reads every row byte once).
+template <bool MAX_ONLY, int NN, int ROW_AUX = 0>
 __global__ __launch_bounds__(kWideThreads, 2) void score_filter_wide_kernel(WideArgs a) {
     constexpr int TQ = 64 * NN;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(kWideThreads, 2) void score_filter_wide_kernel(Wide
     auto request_step = [&]() {
         char* dst = smem + ld_buf * kWideStepBytes;
         request_queries<NN>(qbase, row_bytes, ld_ks * 128, dst, wave, lane_off);
-        request_rows(a.rows, ld_tile * a.tile_stride * kWideTile + wm * 128, a.n - 1, row_bytes, ld_ks * 128,
+        request_rows<ROW_AUX>(a.rows, ld_tile * a.tile_stride * kWideTile + wm * 128, a.n - 1, row_bytes, ld_ks * 128,
                      dst + wm * kHalfBytes, wn, lane, lane_off);
         ld_buf ^= 1;
         if (++ld_ks == ksteps) { ld_ks = 0; ld_tile += tile_step; }
@@ -521,6 +524,15 @@ hipError_t launch_score_wide(const void* rows, int64_t n, int ld, const void* qu
         hipLaunchKernelGGL(kernel, dim3(plan.grid), dim3(kWideThreads), plan.lds, stream, a);
         return hipGetLastError();
     };
+    // streaming row loads: one query tile, full launch, rows beyond the Infinity Cache
+    const int stream_switch = tuning().wide_stream_rows;
+    const bool stream_rows = tile_max == nullptr && (stream_switch >= 0 ? stream_switch != 0
+                                                                        : plan.n_qtiles == 1 && (double)n * ld * 2 > 192.0 * 1024 * 1024);
+    if (stream_rows) {
+        if (plan.tq == 128) return launch(&score_filter_wide_kernel<false, 2, 2>);
+        if (plan.tq == 192) return launch(&score_filter_wide_kernel<false, 3, 2>);
+        if (plan.tq == 256) return launch(&score_filter_wide_kernel<false, 4, 2>);
+    }
     if (plan.tq == 128) return tile_max != nullptr ? launch(&score_filter_wide_kernel<true, 2>) : launch(&score_filter_wide_kernel<false, 2>);
     if (plan.tq == 192) return tile_max != nullptr ? launch(&score_filter_wide_kernel<true, 3>) : launch(&score_filter_wide_kernel<false, 3>);
     if (plan.tq != 256) return hipErrorInvalidValue;
