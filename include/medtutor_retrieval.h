@@ -324,7 +324,9 @@ void mtr_index_destroy(mtr_index_t* index);
  * kernel forms of large shards onto small ones) and timing sweeps; not needed
  * for normal use.  Names: mfma_min_batch, mfma_tnq, mfma_per_cu, mfma_cap,
  * mfma_sample_stride, mfma_stream_rows, mfma_stages, mfma_tile_rows,
- * wide_min_batch, wide_qgroup, scan_wg_per_cu, scan_nontemporal, scan_max_qb,
+ * mfma_interleave, mfma_dynamic_tail, mfma_static_permille, mfma_via_regs,
+ * wide_min_batch, wide_qgroup, wide_tile_queries, wide_stream_rows,
+ * scan_wg_per_cu, scan_nontemporal, scan_max_qb, scan_short_lists,
  * scan_form, scan_static_permille, scan_chunk_groups, scan_mid_permille,
  * scan_pair_permille, scan_late_refill,
  * pool_sliced.  Each starts from the environment variable MTR_<NAME> if set.  Unknown name: MTR_ERR_INVALID.

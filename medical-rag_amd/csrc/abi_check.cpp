@@ -91,6 +91,15 @@ static void plan_checks() {
                                p.grid == p.n_qtiles * p.n_ranges && p.tnq % 16 == 0 && p.tnq >= 16 && p.tnq <= 128 &&
                                (dtype == 0 || !sixteen) && (p.tm == 128 || (p.tm == 256 && p.stages == 3 && dtype == 2)) &&
                                (!sixteen || (p.stages == 2 && p.tm == 128)));
+                        // rows through registers: tall ring form only, whole 512-byte rows, never together with a claimed tail
+                        EXPECT(!p.via_regs || (p.tm == 256 && p.stages == 3 && dtype == 2 && p.stream_rows && !p.dynamic_tail &&
+                                               (p.tnq == 64 || p.tnq == 128) && (ld * 2) % 512 == 0));
+                        mtr::WidePlan w;
+                        if (mtr::plan_wide(dtype, n, ld, b, k, 40 * 64, 256, &w) == 0)
+                            EXPECT((w.tq == 128 || w.tq == 192 || w.tq == 256) && w.n_qtiles * w.tq >= b &&
+                                   (w.n_qtiles - 1) * 256 < b && w.grid == w.n_qtiles * w.n_lists && w.n_lists >= 1 &&
+                                   (w.cap & (w.cap - 1)) == 0 && w.key_bytes == (size_t)w.grid * w.tq * mtr::kWideSubs * w.cap * 8 &&
+                                   w.count_words == (size_t)w.grid * w.tq * mtr::kWideSubs && w.lds <= 160 * 1024);
                         for (int stride : {2, 13, 200}) {
                             const long long stiles = (n + 127) / 128, n_samp = (stiles + stride - 1) / stride;
                             mtr::MfmaPlan s;
