@@ -349,7 +349,24 @@ int enqueue_mfma(mtr_index* ix, S& sc, const mtr::MfmaPlan& plan, const void* de
     // wide kernel starts without floors).
     // The sampling launch works on 128-row tiles whatever the full launch uses.
     const long long stiles = (ix->n + 127) / 128;
-    const int stride = (big && !use_wide) ? sample_stride(ix->n, stiles, k, std::min(b, plan.tnq)) : 0;
+    // The form on 16 x 16 x 32 MFMAs (plan.via_regs == 2) rounds a sum like the filter kernel, not like
+    // the general kernel's other forms: its floors come from the filter kernel's sampling form
+    // (256-row tiles), so that the k rows behind a floor reach it again in the full launch.
+    mtr::WidePlan regs_samp;
+    int rstride = 0;
+    if (big && !use_wide && plan.via_regs == 2) {
+        const long long wtiles = (ix->n + 255) / 256;
+        rstride = sample_stride(ix->n, wtiles, k, std::min(b, plan.tnq));
+        if (rstride >= 2) {
+            const long long n_wsamp = (wtiles + rstride - 1) / rstride;
+            if (n_wsamp > mtr::kMaxSampleTiles ||
+                mtr::plan_wide(ix->dtype, n_wsamp * 256, ix->ld, b, k, 0, ix->num_cus, &regs_samp) != 0 || regs_samp.n_qtiles != 1)
+                return fail(MTR_ERR_INVALID, "internal: no launch shape for the sampling launch of the 16 x 16 form");
+        } else {
+            rstride = 0;
+        }
+    }
+    const int stride = (big && !use_wide && plan.via_regs != 2) ? sample_stride(ix->n, stiles, k, std::min(b, plan.tnq)) : 0;
     mtr::MfmaPlan samp = plan;
     if (stride >= 2) {
         const long long n_samp = (stiles + stride - 1) / stride;
@@ -361,7 +378,7 @@ int enqueue_mfma(mtr_index* ix, S& sc, const mtr::MfmaPlan& plan, const void* de
     // Queries padded to whole tiles: the sampling launch may cut the batch into tiles of another
     // width than the full launch (fewer rows, narrower tiles), and its padded count can be the larger.
     const int padded_q = std::max(plan.n_qtiles * plan.tnq, stride >= 2 ? samp.n_qtiles * samp.tnq : 0);
-    const int64_t q_rows = std::max<int64_t>((int64_t)padded_q, use_wide ? (int64_t)wide.n_qtiles * wide.tq : 0);
+    const int64_t q_rows = std::max<int64_t>((int64_t)padded_q, use_wide ? (int64_t)wide.n_qtiles * wide.tq : rstride ? regs_samp.tq : 0);
     const size_t qbytes = (size_t)q_rows * q_row_bytes;
     const void* q_old = sc.keeps_query_tiles() ? ix->scratch[kQTiles].p : nullptr;
     if ((rc = sc.need(kQTiles, qbytes)) != MTR_OK) return rc;
@@ -377,10 +394,11 @@ int enqueue_mfma(mtr_index* ix, S& sc, const mtr::MfmaPlan& plan, const void* de
         tile_max_bytes = (size_t)wide.n_qtiles * wide.tq * wide_samp.n_tiles * 4;
     }
     if (stride >= 2) tile_max_bytes = std::max<size_t>(tile_max_bytes, (size_t)floor_words * (size_t)samp.n_tiles * 4);
+    if (rstride) tile_max_bytes = std::max<size_t>(tile_max_bytes, (size_t)regs_samp.tq * regs_samp.n_tiles * 4);
     if (tile_max_bytes && (rc = sc.need(kTileMax, tile_max_bytes)) != MTR_OK) return rc;
     if ((rc = sc.ready()) != MTR_OK) return rc;
     // A sampling launch's floor kernel sets every real query's floor; otherwise they start from zero.
-    if (stride < 2) HIP_TRY(mtr::launch_fill_u32(sc.p[kMfmaFloor], 0u, (size_t)floor_words, stream));
+    if (stride < 2 && !rstride) HIP_TRY(mtr::launch_fill_u32(sc.p[kMfmaFloor], 0u, (size_t)floor_words, stream));
     // Query rows past b must be zero.
     char* qbuf = static_cast<char*>(sc.p[kQTiles]);
     if (sc.keeps_query_tiles()) {
@@ -413,6 +431,13 @@ int enqueue_mfma(mtr_index* ix, S& sc, const mtr::MfmaPlan& plan, const void* de
         HIP_TRY(mtr::launch_score_mfma(ix->rows, ix->dtype, ix->n, ix->ld, qbuf, b, k, samp, sampling,
                                        sc.p[kMfmaCand], floors, lists_s, lists_i, stream));
         HIP_TRY(mtr::launch_floor_from_tile_max(tile_max, (int)samp.n_tiles, b, k, floors, stream));
+    }
+    if (rstride) {
+        unsigned int* tile_max = static_cast<unsigned int*>(sc.p[kTileMax]);
+        // the sampling form raises tile_max with atomic maxima: every word starts at zero (below any score)
+        HIP_TRY(mtr::launch_fill_u32(tile_max, 0u, (size_t)regs_samp.tq * regs_samp.n_tiles, stream));
+        HIP_TRY(mtr::launch_score_wide(ix->rows, ix->n, ix->ld, qbuf, b, regs_samp, nullptr, nullptr, nullptr, rstride, tile_max, stream));
+        HIP_TRY(mtr::launch_floor_from_tile_max(tile_max, (int)regs_samp.n_tiles, b, k, floors, stream));
     }
     int* overflow = nullptr;
     if (use_wide) {

@@ -58,7 +58,7 @@ struct Tuning {
     int mfma_dynamic_tail = -1;   // -1: the tall ring forms claim their last tiles from a counter; 0 / 1
     int mfma_static_permille = 0; // ... share of the tiles taken by index in that form (0: 930)
     int mfma_interleave = -1;     // -1: ranges interleaved tile by tile when one query tile streams a large shard; 0 / 1
-    int mfma_via_regs = -1;       // -1: the tall ring form's 128-query tile, and its 64-query tile where it does not claim its tail, take their rows through registers; 0 never; 1 wherever the shape allows
+    int mfma_via_regs = -1;       // -1: the tall ring form's 128-query tile, and its 64-query tile where it does not claim its tail, take their rows through registers (on 16 x 16 x 32 MFMAs); 0 never; 1 wherever the shape allows, on 32 x 32 x 16 MFMAs; 2 wherever the shape allows, on 16 x 16 x 32
     int wide_min_batch = 129;     // smallest batch for the 256 x 256-tile kernel
     int wide_qgroup = 0;          // its query tiles per row list on one XCD (0: four)
     int wide_stream_rows = -1;    // -1: its row loads stream (nt) when one query tile reads a shard beyond the caches; 0 / 1
@@ -175,7 +175,8 @@ struct MfmaPlan {
     int interleave;           // row ranges interleaved tile by tile instead of contiguous stretches
     int dynamic_tail;         // ... and the last tiles claimed from a device-wide counter (needs MfmaPass::sync)
     long long static_tiles;   // tiles every range takes by index in that form
-    int via_regs;             // tall ring form with the rows in flight in registers instead of LDS stages
+    int via_regs;             // tall ring form with the rows in flight in registers instead of LDS stages: 1 on 32 x 32 x 16 MFMAs,
+                              // 2 on 16 x 16 x 32 (a sampling launch must then be the filter kernel's: launch_score_wide with tile_max)
 };
 
 // Launch shape of the matrix-core scoring kernel; -1 when the shape is not

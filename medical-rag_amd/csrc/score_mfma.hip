@@ -193,6 +193,31 @@ __device__ __forceinline__ void mfma_step(float, const char* sa, const char* sb,
     }
 }
 
+// One K step of a wave's sub-tile on v_mfma_f32_16x16x32_bf16: MT16 x NT16 tiles of 16 x 16,
+// the step's 64 elements as two blocks of 32 (lane l supplies row or query l % 16 and elements
+// 8 (l / 16) .. + 7 of a block; it ends up with rows 4 (l / 16) + r, r = 0..3, of query l % 16).
+// The same instruction, operand layout and order of blocks as the 256-row filter kernel
+// (score_wide.hip), so the two kernels' scores are the same bits -- the floors of this form's
+// sampling launch come from that kernel.  The chip holds a higher clock under this
+// instruction than under 32 x 32 x 16 (the same matrix-core cycles and LDS reads).
+template <int MT16, int NT16>
+__device__ __forceinline__ void mfma_step16b(const char* sa, const char* sb, int row_off, int q_off, int lane,
+                                             f32x4v (&acc)[MT16][NT16]) {
+    const int g = lane >> 4, c16 = lane & 15;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        bf16x8 fb[NT16];
+#pragma unroll
+        for (int n = 0; n < NT16; ++n) fb[n] = read_frag(sb, q_off + n * 16 + c16, 4 * kb + g);
+#pragma unroll
+        for (int m = 0; m < MT16; ++m) {
+            const bf16x8 fa = read_frag(sa, row_off + m * 16 + c16, 4 * kb + g);
+#pragma unroll
+            for (int n = 0; n < NT16; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[n], acc[m][n], 0, 0, 0);
+        }
+    }
+}
+
 // The 16- and 48-query tiles of fp32 shards (batches up to 16, and of 33..48):
 // v_mfma_f32_16x16x4_f32, so that a 32- or 64-column tile is not half or a quarter
 // padding -- the fp32 matrix rate, not HBM, is what bounds these batches.  A wave
@@ -297,8 +322,17 @@ __device__ __forceinline__ void lds_store_b128(unsigned int addr, const u32x4& v
 // compiler knows, so the CALLER must not let anything read `dst` before a counted
 // s_waitcnt of its own has covered the load (the compiler's own waits for loads it does
 // track came out as vmcnt(0) inside the loop that keeps four steps in flight).
-__device__ __forceinline__ void load_b128_untracked(u32x4& dst, const char* src) {
-    asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(src) : "memory");
+// (Address: a wave-uniform base in scalar registers plus a 32-bit lane offset, which costs
+// one vector register per load where a 64-bit lane address costs two and an add.)
+// A wave-uniform pointer as one the compiler must keep in scalar registers.
+__device__ __forceinline__ const char* uniform_pointer(const char* p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)v);
+    const unsigned int hi = __builtin_amdgcn_readfirstlane((unsigned int)(v >> 32));
+    return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ void load_b128_untracked(u32x4& dst, const char* base, unsigned int lane_offset) {
+    asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(dst) : "v"(lane_offset), "s"(base) : "memory");
 }
 // "score > own floor && score >= shared floor" as one strict threshold, from the shared
 // floor word as published (order-preserving score bits, 0: none yet): v >= sh is
@@ -367,7 +401,7 @@ __device__ __forceinline__ void append_above(f32x16& tile, float thr, int ql, lo
 }
 
 // The same for one 16 x 16 tile of the 16-query form: query lane % 16, rows row0 + r.
-template <int CAP>
+template <int CAP, bool ASM_ATOMIC = false>
 __device__ __forceinline__ void append_above16(f32x4v& tile, float thr, int ql, long long row0, bool last_tile,
                                                const MfmaArgs& a, int* cnt_lds, unsigned long long* my_buf) {
     const float mx = fmaxf(fmaxf(tile[0], tile[1]), fmaxf(tile[2], tile[3]));
@@ -381,7 +415,7 @@ __device__ __forceinline__ void append_above16(f32x4v& tile, float thr, int ql, 
                 if (row0 + r >= a.n) pass &= ~(1u << r);
         }
         int slot = 0;
-        if (pass) slot = atomicAdd(&cnt_lds[ql], __popc(pass));
+        if (pass) slot = ASM_ATOMIC ? lds_add_return(&cnt_lds[ql], __popc(pass)) : atomicAdd(&cnt_lds[ql], __popc(pass));
         unsigned int any_r = pass;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) any_r |= __shfl_xor(any_r, off, 64);
@@ -515,10 +549,13 @@ __device__ __forceinline__ void write_range_lists(int q0, int nq, int qt_base, i
 constexpr int kRegDepth = 4;
 constexpr int lds_bytes_regs(int tnq) { return 2 * 256 * kStepBytes + (kRegDepth + 1) * tnq * kStepBytes + tnq * 12 + 8 * 1024 + tnq * 4; }
 
-template <typename T, int CAP, int TNQ, bool MAX_ONLY, int ROW_AUX, int NS, int TM = kTileRows, bool DYN = false, bool REGS = false>
+// M16 (with REGS): the sub-tiles as 16 x 16 MFMA tiles (mfma_step16b).
+template <typename T, int CAP, int TNQ, bool MAX_ONLY, int ROW_AUX, int NS, int TM = kTileRows, bool DYN = false, bool REGS = false,
+          bool M16 = false>
 __global__ __launch_bounds__(DYN ? 576 : TM == 256 ? 512 : 256, TM == 256 ? 1 : 2) void score_topk_mfma_kernel(MfmaArgs a) {
     static_assert(!REGS || (NS == 3 && TM == 256 && !MAX_ONLY && !DYN && sizeof(T) == 2 && TNQ % 64 == 0 && ROW_AUX == 2),
                   "rows through registers: tall ring form, bf16, 64 or 128 queries, streaming loads");
+    static_assert(!M16 || REGS, "the 16 x 16 bf16 tiles exist in the rows-through-registers form only");
     static_assert(!DYN || (NS == 3 && TM == 256 && !MAX_ONLY), "claimed tiles exist in the tall ring form only");
     static_assert(NS == 2 || (NS == 3 && !MAX_ONLY), "the ring form exists for the full launch only");
     static_assert(TM == 128 || (TM == 256 && NS == 3), "the tall tile exists in the ring form only");
@@ -622,25 +659,47 @@ __global__ __launch_bounds__(DYN ? 576 : TM == 256 ? 512 : 256, TM == 256 ? 1 : 
             for (int i = tid; i < TN; i += kThreads) fetched_lds[i] = order_f32(shared_lds[i]);
             const int chunk16 = ((lane & 7) ^ (lane >> 3)) * 16;
             u32x4 regs[D][RP];
-            const char* rp[RP];          // this lane's source of each piece, K step 0 of the tile being requested
-            long long ld_t = 0;          // ... which is the workgroup's ld_t-th tile
+            // M16: the wave's sub-tile as 16 x 16 tiles: rows row_off + 16 m + 4 (lane / 16) + r, query q_off + 16 n + lane % 16
+            constexpr int MT16 = M16 ? 2 * MT : 1, NT16 = M16 ? 2 * NT : 1;
+            f32x4v accb[MT16][NT16];
+#pragma unroll
+            for (int m = 0; m < MT16; ++m)
+#pragma unroll
+                for (int n = 0; n < NT16; ++n) accb[m][n] = f32x4v{0.f, 0.f, 0.f, 0.f};
+            // Source of this wave's pieces of the tile being requested (the workgroup's ld_t-th): a scalar base
+            // (the first of the wave's 32 rows) and this lane's offset from it for each piece.
+            const char* src_base = nullptr;
+            unsigned int src_off[RP];
+            long long ld_t = 0;
             int ld_ks = 0;
             auto set_sources = [&](long long t) {
                 const bool real = t < my_tiles;
                 const long long pt = real ? phys(tile_lo + t) : 0;
+                // rows past the end of the matrix are fetched as copies of the last row
+                long long first = pt * TM + wave * (RP * 8);
+                const long long over = first - (a.n - 1);
+                if (over > 0) first = a.n - 1;
+                const long long left = a.n - 1 - first;                      // rows of the matrix beyond the first
+                const int max_r = left > RP * 8 - 1 ? RP * 8 - 1 : (int)left;
+                // past the workgroup's last tile: rows of the query matrix (L2-resident), so that no load sits behind a branch
+                src_base = real ? a.rows + first * row_bytes : qbase + (long long)((wave * (RP * 8)) % TN) * row_bytes;
 #pragma unroll
                 for (int i = 0; i < RP; ++i) {
-                    const int r = (wave * RP + i) * 8 + (lane >> 3);
-                    long long row = pt * TM + r;
-                    row = row < a.n - 1 ? row : a.n - 1;
-                    const char* src = a.rows + row * row_bytes;
-                    const char* idle = qbase + (long long)(r % TN) * row_bytes;
-                    rp[i] = (real ? src : idle) + chunk16;
+                    int r = i * 8 + (lane >> 3);
+                    if (real) r = r < max_r ? r : max_r;
+                    src_off[i] = (unsigned int)r * (unsigned int)row_bytes + (unsigned int)chunk16;
                 }
             };
             auto request_rows = [&](u32x4 (&set)[RP]) {
+                const char* base = uniform_pointer(src_base + ld_ks * kStepBytes);
+                // The base reaches its scalar registers through VALU instructions (v_readfirstlane), and a
+                // memory instruction may read a scalar register a VALU instruction wrote only five wait
+                // states later.  The compiler keeps that distance for instructions it knows; it does not
+                // look into the assembly below, so the distance is made here (without it the first load of
+                // a step went out with the previous step's base: a memory fault).
+                asm volatile("s_nop 4" : "+s"(base));
 #pragma unroll
-                for (int i = 0; i < RP; ++i) load_b128_untracked(set[i], rp[i] + ld_ks * kStepBytes);
+                for (int i = 0; i < RP; ++i) load_b128_untracked(set[i], base, src_off[i]);
                 if (++ld_ks == ksteps) {
                     ld_ks = 0;
                     set_sources(++ld_t);
@@ -653,6 +712,14 @@ __global__ __launch_bounds__(DYN ? 576 : TM == 256 ? 512 : 256, TM == 256 ? 1 : 
                 q_stage = q_stage + 1 == QR ? 0 : q_stage + 1;
             };
             int q_cur = 0;               // the stage the MFMAs read
+            static_assert(RP == 4, "four pieces per wave and step");
+            auto store_pieces = [&](auto stage_offset, const u32x4 (&set)[RP]) {
+                constexpr int O = decltype(stage_offset)::value;
+                lds_store_b128<O>(row_dst, set[0]);
+                lds_store_b128<O + 1024>(row_dst, set[1]);
+                lds_store_b128<O + 2048>(row_dst, set[2]);
+                lds_store_b128<O + 3072>(row_dst, set[3]);
+            };
             // One K step; J = step % 4 picks the register set and the row stage at compile time.
             auto step = [&](auto jc) {
                 constexpr int J = decltype(jc)::value;
@@ -663,16 +730,15 @@ __global__ __launch_bounds__(DYN ? 576 : TM == 256 ? 512 : 256, TM == 256 ? 1 : 
                 barrier_keeping_loads();
                 // every wave is past the MFMAs of step s - 1: its row stage takes step s + 1 ...
                 if (!(MTR_TIMING(a) & 64)) {
-#pragma unroll
-                    for (int i = 0; i < RP; ++i) {
-                        if constexpr (((J + 1) & 1) == 0) lds_store_b128<0>(row_dst + i * 1024, regs[SET][i]);
-                        else lds_store_b128<kRowStage>(row_dst + i * 1024, regs[SET][i]);
-                    }
+                    store_pieces(std::integral_constant<int, ((J + 1) & 1) * kRowStage>{}, regs[SET]);
                 }
                 // ... its registers step s + 1 + D, and the query stage of step s - 1 step s + D
                 request_rows(regs[SET]);
                 request_queries();
-                if (!(MTR_TIMING(a) & 32)) mfma_step<MT, NT>(T{}, smem + (J & 1) * kRowStage, qstage + q_cur * kQStage, row_off, q_off, lane, acc);
+                if (!(MTR_TIMING(a) & 32)) {
+                    if constexpr (M16) mfma_step16b<MT16, NT16>(smem + (J & 1) * kRowStage, qstage + q_cur * kQStage, row_off, q_off, lane, accb);
+                    else mfma_step<MT, NT>(T{}, smem + (J & 1) * kRowStage, qstage + q_cur * kQStage, row_off, q_off, lane, acc);
+                }
                 q_cur = q_cur + 1 == QR ? 0 : q_cur + 1;
             };
             // Nothing but the loads below may be in flight when the counted waits start.
@@ -687,8 +753,7 @@ __global__ __launch_bounds__(DYN ? 576 : TM == 256 ? 512 : 256, TM == 256 ? 1 : 
             request_queries();
             // step "-1": the first step's rows go into stage 0
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * (RP + QP)) : "memory");
-#pragma unroll
-            for (int i = 0; i < RP; ++i) lds_store_b128<0>(row_dst + i * 1024, regs[0][i]);
+            store_pieces(std::integral_constant<int, 0>{}, regs[0]);
             request_rows(regs[0]);
             request_queries();
             for (long long t = 0; t < my_tiles; ++t) {
@@ -704,15 +769,27 @@ __global__ __launch_bounds__(DYN ? 576 : TM == 256 ? 512 : 256, TM == 256 ? 1 : 
                     step(std::integral_constant<int, 3>{});
                     kg += D;
                 } while (kg < ksteps);
-                const long long row_base = ptile * TM + row_off + 4 * (lane >> 5);
                 const bool last_tile = (ptile + 1) * TM > a.n;
+                if constexpr (M16) {
+                    const long long row_base = ptile * TM + row_off + 4 * (lane >> 4);
 #pragma unroll
-                for (int n = 0; n < NT; ++n) {
-                    const int ql = q_off + n * 32 + (lane & 31);
-                    const float thr = strict_threshold(floor_lds[ql], fetched_lds[ql]);
+                    for (int n = 0; n < NT16; ++n) {
+                        const int ql = q_off + n * 16 + (lane & 15);
+                        const float thr = strict_threshold(floor_lds[ql], fetched_lds[ql]);
 #pragma unroll
-                    for (int m = 0; m < MT; ++m)
-                        append_above<CAP, true>(acc[m][n], thr, ql, row_base + m * 32, last_tile, a, cnt_lds, my_buf);
+                        for (int m = 0; m < MT16; ++m)
+                            append_above16<CAP, true>(accb[m][n], thr, ql, row_base + m * 16, last_tile, a, cnt_lds, my_buf);
+                    }
+                } else {
+                    const long long row_base = ptile * TM + row_off + 4 * (lane >> 5);
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        const int ql = q_off + n * 32 + (lane & 31);
+                        const float thr = strict_threshold(floor_lds[ql], fetched_lds[ql]);
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+                            append_above<CAP, true>(acc[m][n], thr, ql, row_base + m * 32, last_tile, a, cnt_lds, my_buf);
+                    }
                 }
                 barrier_keeping_loads();  // the counts of this tile are visible
                 if (any_buffer_full<CAP, TN>(cnt_lds, TM, lane)) {
@@ -1151,7 +1228,9 @@ int plan_mfma(int dtype, int64_t n, int ld, int b, int k, int num_cus, int sampl
         // (the 64-query tile gains 0.3 % where it does not claim its tail, nothing where it does)
         const bool want = tn.mfma_via_regs >= 0 ? tn.mfma_via_regs != 0 : plan->tnq == 128 || !plan->dynamic_tail;
         if (can && want) {
-            plan->via_regs = 1;
+            // 2: on 16 x 16 x 32 MFMAs (the chip holds a higher clock under them; floors then come from the
+            // filter kernel's sampling form, which multiplies the same way); 1: on 32 x 32 x 16 like the other forms
+            plan->via_regs = tn.mfma_via_regs == 1 ? 1 : 2;
             plan->dynamic_tail = 0;
             plan->static_tiles = 0;
             plan->lds = lds_bytes_regs(plan->tnq);
@@ -1252,6 +1331,8 @@ hipError_t launch_score_mfma(const void* rows, int dtype, int64_t n, int ld, con
 #undef MTR_MFMA_PICK16
     if (plan.tm == 256) {
         if (plan.stages != 3 || plan.cap != 512 || dtype != 2 || a.tile_max != nullptr) return hipErrorInvalidValue;
+        if (plan.via_regs == 2 && plan.tnq == 64) return launch(&score_topk_mfma_kernel<bf16_t, 512, 64, false, 2, 3, 256, false, true, true>);
+        if (plan.via_regs == 2 && plan.tnq == 128) return launch(&score_topk_mfma_kernel<bf16_t, 512, 128, false, 2, 3, 256, false, true, true>);
         if (plan.via_regs && plan.tnq == 64) return launch(&score_topk_mfma_kernel<bf16_t, 512, 64, false, 2, 3, 256, false, true>);
         if (plan.via_regs && plan.tnq == 128) return launch(&score_topk_mfma_kernel<bf16_t, 512, 128, false, 2, 3, 256, false, true>);
         if (dyn && plan.tnq == 32) return launch(&score_topk_mfma_kernel<bf16_t, 512, 32, false, 2, 3, 256, true>);

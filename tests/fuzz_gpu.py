@@ -27,7 +27,7 @@ for case in range(cases):
         if rng.random() < 0.3: opts["mfma_tile_rows"] = int(rng.choice([128, 256]))
         if store == "bf16" and rng.random() < 0.3: opts["wide_min_batch"] = 1
         if rng.random() < 0.2: opts["mfma_min_batch"] = int(rng.choice([2, 100]))
-        if rng.random() < 0.5: opts["mfma_via_regs"] = int(rng.integers(0, 2))
+        if rng.random() < 0.5: opts["mfma_via_regs"] = int(rng.integers(0, 3))
     corpus = rng.integers(-3, 4, size=(n, d)).astype(np.float32)
     queries = rng.integers(-3, 4, size=(b, d)).astype(np.float32)
     shard = N.DeviceShard.from_host(corpus, store_dtype=store, normalize=False, row_offset=int(rng.choice([0, 12345])))

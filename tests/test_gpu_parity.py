@@ -598,7 +598,7 @@ def test_forced_kernel_forms_are_exact_on_random_integer_shapes(native, store):
         k = int(rng.choice([1, 5, 10, 33, 100, 256]))
         stride = int(rng.choice([0, 2, 7]))
         env = dict(MTR_MFMA_STREAM_ROWS=1, MTR_MFMA_STAGES=int(rng.choice([2, 3])), MTR_MFMA_SAMPLE_STRIDE=stride,
-                   MTR_MFMA_VIA_REGS=1)   # rows through registers wherever the shape has that form (rows of whole 512 bytes)
+                   MTR_MFMA_VIA_REGS=1 + case % 2)   # rows through registers, on either matrix instruction, wherever the shape has that form (rows of whole 512 bytes)
         if store == "bf16" and case % 2 == 0:
             env["MTR_WIDE_MIN_BATCH"] = 1
         corpus = rng.integers(-3, 4, size=(n, d)).astype(np.float32)

@@ -159,11 +159,15 @@ def test_matrix_core_ring_with_claimed_tail(native, n, d, b):
 def test_matrix_core_ring_with_rows_through_registers(native, n, d, b, k):
     """The tall ring form whose rows stay in flight in registers (four K steps per
     wave, written into two LDS stages a step ahead; the query tile in a ring of
-    five), forced onto small shards: integer rows, so ids and scores equal the
-    oracle bit for bit; on real-valued rows the same bits as the form that loads
-    rows straight into LDS (same order of a row's products); with and without a
-    sampling launch; searched three times in a row; a shard of fewer tiles than
-    workgroups and a ragged last tile included."""
+    five), forced onto small shards, on both matrix instructions (switch value 1:
+    32 x 32 x 16 like the other forms; 2: 16 x 16 x 32 like the 256-row filter
+    kernel, whose sampling form then provides the floors).  Integer rows: ids and
+    scores equal the oracle bit for bit.  Real-valued rows: form 1 returns the bits
+    of the form that loads rows straight into LDS, form 2 the bits of the filter
+    kernel (same instruction, same order of a sum's terms), and the two agree up to
+    swaps among scores equal to 1e-6.  With and without a sampling launch; searched
+    several times in a row; a shard of fewer tiles than workgroups and a ragged
+    last tile included."""
     import torch
     rng = np.random.default_rng(n + d + b)
     forms = dict(mfma_stream_rows=1, mfma_stages=3, mfma_tile_rows=256, mfma_dynamic_tail=0)
@@ -172,13 +176,14 @@ def test_matrix_core_ring_with_rows_through_registers(native, n, d, b, k):
     corpus[n - 1] = queries[0]
     shard = native.DeviceShard.from_host(corpus, store_dtype="bf16", normalize=False)
     want_i, want_s = orc.search(queries, corpus, k, metric="ip")
-    for stride in (0, 3):
-        with native.options(mfma_via_regs=1, mfma_sample_stride=stride, **forms):
-            for _ in range(2):
-                idx, score = shard.search(queries, k=k, metric="ip")
-                assert shard.last_kernel() == "score_topk_mfma_kernel"
-                assert (idx == want_i).all(), (n, d, b, stride)
-                assert (score == want_s.astype(np.float32)).all(), (n, d, b, stride)
+    for form in (1, 2):
+        for stride in (0, 3):
+            with native.options(mfma_via_regs=form, mfma_sample_stride=stride, **forms):
+                for _ in range(2):
+                    idx, score = shard.search(queries, k=k, metric="ip")
+                    assert shard.last_kernel() == "score_topk_mfma_kernel"
+                    assert (idx == want_i).all(), (n, d, b, form, stride)
+                    assert (score == want_s.astype(np.float32)).all(), (n, d, b, form, stride)
     shard.close()
     gen = torch.Generator(device="cuda").manual_seed(n)
     rows = torch.randn((n, d), generator=gen, device="cuda")
@@ -192,4 +197,21 @@ def test_matrix_core_ring_with_rows_through_registers(native, n, d, b, k):
             di, ds = (t.clone() for t in shard.search_device(q, k=k))
             torch.cuda.synchronize()
             assert torch.equal(ei, di) and torch.equal(es, ds)
+    if n >= 256 * 2 * k * 3:   # the filter kernel always samples: at least 2k sampled tiles
+        with native.options(wide_min_batch=1, mfma_sample_stride=3):
+            wi, ws = (t.clone() for t in shard.search_device(q, k=k))
+            assert shard.last_kernel() == "score_filter_wide_kernel"
+    else:
+        wi = ws = None
+    for stride in (0, 3):
+        with native.options(mfma_via_regs=2, mfma_sample_stride=stride, **forms):
+            for _ in range(2):
+                mi, ms = (t.clone() for t in shard.search_device(q, k=k))
+                torch.cuda.synchronize()
+                if wi is not None:
+                    assert torch.equal(wi, mi) and torch.equal(ws, ms), (n, d, b, stride)
+                assert float((ms - es).abs().max()) <= 1e-6
+                differ = mi != ei
+                if bool(differ.any()):   # a swap inside a run of scores equal to the last bit or two
+                    assert float((ms[differ] - es[differ]).abs().max()) <= 1e-6 and float(differ.float().mean()) < 0.01
     shard.close()
