@@ -187,13 +187,16 @@ def test_device_path_reports_nonfinite_queries(native):
     shard.close()
 
 
-@pytest.mark.parametrize("store,n,d,batches", [("fp32", 1_000_000, 768, (1,)), ("bf16", 10_000_000, 1024, (1, 64)),
-                                               ("bf16", 12_500_000, 768, (1, 64))])
+@pytest.mark.parametrize("store,n,d,batches", [("fp32", 1_000_000, 768, (1,)), ("bf16", 10_000_000, 1024, (1, 64, 128, 192)),
+                                               ("bf16", 12_500_000, 768, (1, 64, 100))])
 def test_benchmark_shapes(native, store, n, d, batches):
     """The shapes the benchmark numbers are quoted on, with the library's own
     launch rules (no switches): 1M x 768 fp32 and 10M x 1024 bf16 with a single
     query, the latter and one GPU's 12.5M x 768 bf16 share of the 100M-row corpus
-    also with a 64-query batch.  Rows are generated on the GPU; k rows per query
+    also with a 64-query batch, with 100 or 128 queries (the general kernel's form
+    that keeps rows in flight in registers, behind the filter kernel's sampling
+    form) and with 192 (the filter kernel with a 192-wide query tile and streaming
+    rows).  Rows are generated on the GPU; k rows per query
     are planted for the first four queries and must come back, in order; the
     oracle re-scores the original fp32 rows of (returned rows U 100k random rows);
     a repeated search is identical."""
