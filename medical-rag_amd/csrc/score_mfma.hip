@@ -546,10 +546,14 @@ __device__ __forceinline__ void write_range_lists(int q0, int nq, int qt_base, i
 // ahead as the rows, because a wave's loads complete in order: waiting for a young query
 // piece would wait for every older row load too.  Past its last tile a workgroup keeps
 // requesting (from the query matrix, which is in L2) so that no load sits behind a branch.
+// What is left between this form and the scan's time at 65..128 queries is the power limit:
+// with random queries the chip holds 1.8 GHz under it where the scan runs at 2.4 GHz, and the
+// same launch with all-zero queries takes 3.05 instead of 3.45-3.67 ms.
 constexpr int kRegDepth = 4;
 constexpr int lds_bytes_regs(int tnq) { return 2 * 256 * kStepBytes + (kRegDepth + 1) * tnq * kStepBytes + tnq * 12 + 8 * 1024 + tnq * 4; }
 
-// M16 (with REGS): the sub-tiles as 16 x 16 MFMA tiles (mfma_step16b).
+// M16 (with REGS): the sub-tiles as 16 x 16 MFMA tiles (mfma_step16b): 4 % faster at 128 queries,
+// and the filter kernel's arithmetic, so its sampling form must provide the floors.
 template <typename T, int CAP, int TNQ, bool MAX_ONLY, int ROW_AUX, int NS, int TM = kTileRows, bool DYN = false, bool REGS = false,
           bool M16 = false>
 __global__ __launch_bounds__(DYN ? 576 : TM == 256 ? 512 : 256, TM == 256 ? 1 : 2) void score_topk_mfma_kernel(MfmaArgs a) {
