@@ -359,9 +359,10 @@ int enqueue_mfma(mtr_index* ix, S& sc, const mtr::MfmaPlan& plan, const void* de
         rstride = sample_stride(ix->n, wtiles, k, std::min(b, plan.tnq));
         if (rstride >= 2) {
             const long long n_wsamp = (wtiles + rstride - 1) / rstride;
+            // (a forced combination of switches the sampling form has no shape for: search without floors)
             if (n_wsamp > mtr::kMaxSampleTiles ||
                 mtr::plan_wide(ix->dtype, n_wsamp * 256, ix->ld, b, k, 0, ix->num_cus, &regs_samp) != 0 || regs_samp.n_qtiles != 1)
-                return fail(MTR_ERR_INVALID, "internal: no launch shape for the sampling launch of the 16 x 16 form");
+                rstride = 0;
         } else {
             rstride = 0;
         }
