@@ -108,6 +108,24 @@ static void plan_checks() {
                         }
                     }
     EXPECT(checked > 10000);
+    // The forms the benchmark shapes are measured on (default switches, 256 CUs).
+    {
+        mtr::MfmaPlan p;
+        EXPECT(mtr::plan_mfma(2, 10000000, 1024, 128, 10, 256, 0, &p) == 0 && p.tnq == 128 && p.tm == 256 && p.stages == 3 &&
+               p.stream_rows && p.interleave && p.via_regs == 2 && !p.dynamic_tail && p.n_qtiles == 1);
+        EXPECT(mtr::plan_mfma(2, 10000000, 1024, 96, 10, 256, 0, &p) == 0 && p.tnq == 128 && p.via_regs == 2);
+        EXPECT(mtr::plan_mfma(2, 10000000, 1024, 64, 10, 256, 0, &p) == 0 && p.tnq == 64 && p.tm == 256 && p.via_regs == 2 && !p.dynamic_tail);
+        EXPECT(mtr::plan_mfma(2, 12500000, 768, 64, 10, 256, 0, &p) == 0 && p.tnq == 64 && p.tm == 256 && p.dynamic_tail && !p.via_regs);
+        EXPECT(mtr::plan_mfma(2, 10000000, 1024, 32, 10, 256, 0, &p) == 0 && p.tnq == 32 && p.dynamic_tail && !p.via_regs);
+        EXPECT(mtr::plan_mfma(2, 12500000, 768, 128, 10, 256, 0, &p) == 0 && p.tnq == 128 && p.via_regs == 2);
+        EXPECT(mtr::plan_mfma(2, 4032, 1024, 100, 10, 256, 0, &p) == 0 && !p.stream_rows && !p.via_regs);   // a shard within the caches
+        EXPECT(mtr::plan_mfma(0, 1000000, 768, 34, 10, 256, 0, &p) == 0 && p.tnq == 48 && !p.via_regs);     // fp32: 16 x 16 tiles, two buffers
+        mtr::WidePlan w;
+        EXPECT(mtr::plan_wide(2, 10000000, 1024, 129, 10, 2000, 256, &w) == 0 && w.tq == 192 && w.n_qtiles == 1);
+        EXPECT(mtr::plan_wide(2, 10000000, 1024, 256, 10, 2000, 256, &w) == 0 && w.tq == 256 && w.n_qtiles == 1);
+        EXPECT(mtr::plan_wide(2, 1000000, 1024, 384, 10, 2000, 256, &w) == 0 && w.tq == 192 && w.n_qtiles == 2);
+        EXPECT(mtr::plan_wide(2, 1000000, 1024, 4096, 100, 8000, 256, &w) == 0 && w.tq == 256 && w.n_qtiles == 16 && w.n_lists == 16);
+    }
 }
 
 int main() {
